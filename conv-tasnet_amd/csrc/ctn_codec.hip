@@ -1,0 +1,239 @@
+// Encoder / decoder glue kernels around the MFMA GEMMs, gfx950.  All HBM-bound, frames on lanes.
+//
+//  encoder  (src/conv_tasnet.py:106-121):  w = relu(U . frames(x))      = im2col + ctn_pw_gemm(act=relu)
+//  decoder  (src/conv_tasnet.py:140-145):  est = OLA(V . (w * mask))    = mask_apply + ctn_pw_gemm + ola
+//  overlap_and_add (src/utils.py:9-47) is a gather here (each output sample sums the <= ceil(L/S)
+//  frame taps that cover it): deterministic, no atomics, unlike index_add_.
+#include "ctn_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXC = 8;   // max speakers for the softmax mask
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Xcol[m][l][k] = x[m][k*S + l]  (k < K, l < L), zero elsewhere.  Xcol is [M, Lp, Kp].
+__global__ __launch_bounds__(NT) void im2col_kernel(const float* __restrict__ x, float* __restrict__ xc,
+                                                    int M, int T, int L, int Lp, int S, int K, int Kp) {
+    const long long n = (long long)M * Lp * Kp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int k = (int)(i % Kp);
+        const int l = (int)((i / Kp) % Lp);
+        const int m = (int)(i / ((long long)Kp * Lp));
+        float v = 0.f;
+        if (k < K && l < L) v = x[(size_t)m * T + (size_t)k * S + l];
+        xc[i] = v;
+    }
+}
+
+// sw[m,c,n,k] = w[m,n,k] * act(score[m,c,n,k]);  act = relu (mode 0) or softmax over c (mode 1)
+__global__ __launch_bounds__(NT) void mask_apply_kernel(const float* __restrict__ score, const float* __restrict__ w,
+                                                        float* __restrict__ sw, int M, int C, long long NK, int mode) {
+    const long long n4 = (long long)M * NK / 4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        const long long e = i * 4;
+        const int m = (int)(e / NK);
+        const long long r = e % NK;
+        const float4 wv = ld4(w + e);
+        const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+        const size_t base = (size_t)m * C * NK + r;
+        if (mode == 0) {
+            for (int c = 0; c < C; ++c) {
+                const float4 s = ld4(score + base + (size_t)c * NK);
+                *reinterpret_cast<float4*>(sw + base + (size_t)c * NK) =
+                    make_float4(ww[0] * fmaxf(s.x, 0.f), ww[1] * fmaxf(s.y, 0.f), ww[2] * fmaxf(s.z, 0.f), ww[3] * fmaxf(s.w, 0.f));
+            }
+        } else {
+            float sc[MAXC][4];
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+                    const float4 s = ld4(score + base + (size_t)c * NK);
+                    sc[c][0] = s.x; sc[c][1] = s.y; sc[c][2] = s.z; sc[c][3] = s.w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mx[q] = fmaxf(mx[q], sc[c][q]);
+                }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { sc[c][q] = expf(sc[c][q] - mx[q]); den[q] += sc[c][q]; }
+                }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C)
+                    *reinterpret_cast<float4*>(sw + base + (size_t)c * NK) =
+                        make_float4(ww[0] * (sc[c][0] / den[0]), ww[1] * (sc[c][1] / den[1]),
+                                    ww[2] * (sc[c][2] / den[2]), ww[3] * (sc[c][3] / den[3]));
+        }
+    }
+}
+
+// backward of mask_apply: dscore (may alias dsw) and dw[m,n,k] = sum_c dsw*mask
+__global__ __launch_bounds__(NT) void mask_apply_bwd_kernel(const float* __restrict__ dsw, const float* __restrict__ score,
+                                                            const float* __restrict__ w, float* __restrict__ dscore,
+                                                            float* __restrict__ dw, int M, int C, long long NK, int mode) {
+    const long long n4 = (long long)M * NK / 4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        const long long e = i * 4;
+        const int m = (int)(e / NK);
+        const long long r = e % NK;
+        const float4 wv = ld4(w + e);
+        const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+        const size_t base = (size_t)m * C * NK + r;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mode == 0) {
+            for (int c = 0; c < C; ++c) {
+                const float4 s = ld4(score + base + (size_t)c * NK);
+                const float4 g = ld4(dsw + base + (size_t)c * NK);
+                const float sv[4] = {s.x, s.y, s.z, s.w}, gv[4] = {g.x, g.y, g.z, g.w};
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] += gv[q] * fmaxf(sv[q], 0.f);
+                    o[q] = sv[q] > 0.f ? gv[q] * ww[q] : 0.f;
+                }
+                *reinterpret_cast<float4*>(dscore + base + (size_t)c * NK) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            float pr[MAXC][4], gm[MAXC][4];
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, den[4] = {0.f, 0.f, 0.f, 0.f}, dotv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+                    const float4 s = ld4(score + base + (size_t)c * NK);
+                    const float4 g = ld4(dsw + base + (size_t)c * NK);
+                    pr[c][0] = s.x; pr[c][1] = s.y; pr[c][2] = s.z; pr[c][3] = s.w;
+                    gm[c][0] = g.x; gm[c][1] = g.y; gm[c][2] = g.z; gm[c][3] = g.w;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mx[q] = fmaxf(mx[q], pr[c][q]);
+                }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { pr[c][q] = expf(pr[c][q] - mx[q]); den[q] += pr[c][q]; }
+                }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pr[c][q] /= den[q];
+                        acc[q] += gm[c][q] * pr[c][q];          // dw
+                        gm[c][q] *= ww[q];                      // dmask
+                        dotv[q] += gm[c][q] * pr[c][q];
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C)
+                    *reinterpret_cast<float4*>(dscore + base + (size_t)c * NK) =
+                        make_float4(pr[c][0] * (gm[c][0] - dotv[0]), pr[c][1] * (gm[c][1] - dotv[1]),
+                                    pr[c][2] * (gm[c][2] - dotv[2]), pr[c][3] * (gm[c][3] - dotv[3]));
+        }
+        *reinterpret_cast<float4*>(dw + e) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// est[b][t] = sum_{k,l: k*S+l = t} fr[b][l][k],  b over M*C rows; est is [B, T], zero for t >= (K-1)S+L
+__global__ __launch_bounds__(NT) void ola_kernel(const float* __restrict__ fr, float* __restrict__ est,
+                                                 int Bn, int T, int L, int Lp, int S, int K, int Kp) {
+    const long long n = (long long)Bn * T;
+    const int q = (L + S - 1) / S;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int t = (int)(i % T);
+        const int b = (int)(i / T);
+        const float* __restrict__ f = fr + (size_t)b * Lp * Kp;
+        const int kh = t / S;
+        float v = 0.f;
+        for (int j = q - 1; j >= 0; --j) {        // ascending frame index, like the reference's accumulation order
+            const int k = kh - j, l = t - k * S;
+            if (k >= 0 && k < K && l < L) v += f[(size_t)l * Kp + k];
+        }
+        est[i] = v;
+    }
+}
+
+// dfr[b][l][k] = (k < K && l < L) ? dest[b][k*S + l] : 0
+__global__ __launch_bounds__(NT) void unfold_kernel(const float* __restrict__ dest, float* __restrict__ dfr,
+                                                    int Bn, int T, int L, int Lp, int S, int K, int Kp) {
+    const long long n = (long long)Bn * Lp * Kp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int k = (int)(i % Kp);
+        const int l = (int)((i / Kp) % Lp);
+        const int b = (int)(i / ((long long)Kp * Lp));
+        float v = 0.f;
+        if (k < K && l < L) v = dest[(size_t)b * T + (size_t)k * S + l];
+        dfr[i] = v;
+    }
+}
+
+unsigned grid_for(long long n) {
+    long long b = ctn_cdivll(n, NT);
+    if (b > 256 * 16) b = 256 * 16;   // grid-stride beyond 16 workgroups per CU
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ctn_im2col(const float* mix, float* xcol, int M, int T, int L, int Lp, int K, int Kp, void* stream) {
+    CTN_REQUIRE(mix && xcol, "ctn_im2col: null pointer");
+    CTN_REQUIRE(M > 0 && L >= 2 && Lp >= L && T >= L && K == (T - L) / (L / 2) + 1 && Kp >= K,
+                "ctn_im2col: inconsistent sizes (T=%d L=%d K=%d Kp=%d)", T, L, K, Kp);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((long long)M * Lp * Kp)), dim3(NT), 0, (hipStream_t)stream,
+                       mix, xcol, M, T, L, Lp, L / 2, K, Kp);
+    CTN_CHECK_LAUNCH("ctn_im2col");
+    return CTN_OK;
+}
+
+int ctn_mask_apply(const float* score, const float* w, float* sw, int M, int C, int N, int Kp, int softmax, void* stream) {
+    CTN_REQUIRE(score && w && sw, "ctn_mask_apply: null pointer");
+    CTN_REQUIRE(M > 0 && C > 0 && N > 0 && Kp > 0 && Kp % 4 == 0, "ctn_mask_apply: bad sizes");
+    CTN_REQUIRE(!softmax || C <= MAXC, "ctn_mask_apply: softmax mask supports at most %d speakers", MAXC);
+    CTN_REQUIRE(aligned16(score) && aligned16(w) && aligned16(sw), "ctn_mask_apply: alignment");
+    const long long NK = (long long)N * Kp;
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for((long long)M * NK / 4)), dim3(NT), 0, (hipStream_t)stream,
+                       score, w, sw, M, C, NK, softmax ? 1 : 0);
+    CTN_CHECK_LAUNCH("ctn_mask_apply");
+    return CTN_OK;
+}
+
+int ctn_mask_apply_bwd(const float* dsw, const float* score, const float* w, float* dscore, float* dw,
+                       int M, int C, int N, int Kp, int softmax, void* stream) {
+    CTN_REQUIRE(dsw && score && w && dscore && dw, "ctn_mask_apply_bwd: null pointer");
+    CTN_REQUIRE(M > 0 && C > 0 && N > 0 && Kp > 0 && Kp % 4 == 0, "ctn_mask_apply_bwd: bad sizes");
+    CTN_REQUIRE(!softmax || C <= MAXC, "ctn_mask_apply_bwd: softmax mask supports at most %d speakers", MAXC);
+    CTN_REQUIRE(aligned16(dsw) && aligned16(score) && aligned16(w) && aligned16(dscore) && aligned16(dw), "ctn_mask_apply_bwd: alignment");
+    const long long NK = (long long)N * Kp;
+    hipLaunchKernelGGL(mask_apply_bwd_kernel, dim3(grid_for((long long)M * NK / 4)), dim3(NT), 0, (hipStream_t)stream,
+                       dsw, score, w, dscore, dw, M, C, NK, softmax ? 1 : 0);
+    CTN_CHECK_LAUNCH("ctn_mask_apply_bwd");
+    return CTN_OK;
+}
+
+int ctn_ola(const float* frames, float* est, int Bn, int T, int L, int Lp, int K, int Kp, void* stream) {
+    CTN_REQUIRE(frames && est, "ctn_ola: null pointer");
+    CTN_REQUIRE(Bn > 0 && L >= 2 && Lp >= L && K > 0 && Kp >= K && T >= (K - 1) * (L / 2) + L, "ctn_ola: inconsistent sizes");
+    hipLaunchKernelGGL(ola_kernel, dim3(grid_for((long long)Bn * T)), dim3(NT), 0, (hipStream_t)stream,
+                       frames, est, Bn, T, L, Lp, L / 2, K, Kp);
+    CTN_CHECK_LAUNCH("ctn_ola");
+    return CTN_OK;
+}
+
+int ctn_unfold(const float* dest, float* dframes, int Bn, int T, int L, int Lp, int K, int Kp, void* stream) {
+    CTN_REQUIRE(dest && dframes, "ctn_unfold: null pointer");
+    CTN_REQUIRE(Bn > 0 && L >= 2 && Lp >= L && K > 0 && Kp >= K && T >= (K - 1) * (L / 2) + L, "ctn_unfold: inconsistent sizes");
+    hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long long)Bn * Lp * Kp)), dim3(NT), 0, (hipStream_t)stream,
+                       dest, dframes, Bn, T, L, Lp, L / 2, K, Kp);
+    CTN_CHECK_LAUNCH("ctn_unfold");
+    return CTN_OK;
+}
+
+}  // extern "C"

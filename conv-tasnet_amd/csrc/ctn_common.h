@@ -1,0 +1,89 @@
+// Shared device/host helpers for the Conv-TasNet gfx950 kernels.
+// gfx950 only: wave = 64 lanes, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define CTN_EPS 1e-8f   // EPS of src/conv_tasnet.py:10 and src/pit_criterion.py:9
+
+// ---- status / error reporting across the C ABI (never throws) -------------
+enum {
+    CTN_OK = 0,
+    CTN_ERR_ARG = -1,      // bad shape / null pointer / unsupported size
+    CTN_ERR_LAUNCH = -2,   // hipGetLastError() after a launch
+    CTN_ERR_WORKSPACE = -3 // caller-provided workspace too small
+};
+
+void ctn_set_error(const char* fmt, ...);
+
+#define CTN_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            ctn_set_error(__VA_ARGS__);                         \
+            return CTN_ERR_ARG;                                 \
+        }                                                       \
+    } while (0)
+
+#define CTN_CHECK_LAUNCH(name)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            ctn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return CTN_ERR_LAUNCH;                                          \
+        }                                                                   \
+    } while (0)
+
+static inline int ctn_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long ctn_cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---- wave64 / block reductions ---------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over a whole block of NT threads (NT multiple of 64, <= 1024).
+// Result valid in every thread.  `scratch` holds >= NT/64 elements of T.
+// The order of additions is fixed -> bitwise reproducible.
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+    constexpr int NW = NT / 64;
+    v = wave_sum(v);
+    __syncthreads();  // scratch may still be read by a previous call
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T r = scratch[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r += scratch[w];
+    return r;
+}
+
+__device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
+
+// Finalise (mean, rstd) of one utterance from [nparts][2] double partial (sum, sumsq).
+// Every thread of the block returns the same values.  count = Ch*K valid elements.
+template <int NT>
+__device__ __forceinline__ void finalize_stats(const double* __restrict__ part, int nparts, double count,
+                                               double* scratch, float& mean, float& rstd) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += NT) {
+        s += part[2 * i];
+        q += part[2 * i + 1];
+    }
+    s = block_sum<double, NT>(s, scratch);
+    q = block_sum<double, NT>(q, scratch);
+    const double mu = s / count;
+    double var = q / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)CTN_EPS));
+}
+#endif  // __HIPCC__

@@ -1,0 +1,619 @@
+// HBM-bound kernels of the temporal-conv blocks, gfx950.
+//
+//  * depthwise dilated conv forward/backward (src/conv_tasnet.py:247-295) with the
+//    neighbouring PReLU + global-LayerNorm (:224-225, :259-260, :338-361) fused in:
+//    one wave owns one (utterance, channel) row, frames on the lanes (coalesced
+//    256-B / 1-KiB wave accesses), the P-tap dilated window is served from an
+//    LDS copy of the row segment (+halo) that already holds the normalised values.
+//  * element-wise gLN+PReLU backward.
+//  * channel-wise LayerNorm (:313-335) forward / backward for the causal variant
+//    and the input norm (:172).
+//  * small fixed-order reductions for per-channel parameter gradients.
+//
+// All cross-lane / cross-block sums have a fixed order (no float atomics), so a
+// step is bitwise reproducible run to run.
+#include "ctn_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int ROWS = 4;          // one wave per row
+constexpr int MAXP = 8;          // max depthwise kernel size supported
+constexpr int FWD_BUF = 3584;    // floats of LDS per wave (forward): 56 KiB / block
+constexpr int BWD_BUF = 1792;    // floats per wave per array (backward, two arrays): 56 KiB / block
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ int floor4(int v) { return (v >> 2) << 2; }  // arithmetic shift: floors negatives
+
+// ---------------------------------------------------------------------------
+// depthwise forward:  z[k] = sum_j D[c,j] * n[k + j*dil - padl],  n = (PRO ? gLN(prelu(y)) : y)
+// ---------------------------------------------------------------------------
+struct DwFwdArgs {
+    const float* Y; float* Z; const float* D;
+    int M, H, K, Kp, P, dil, padl, seg;
+    const double* pro_part; int pro_nparts;
+    const float* pro_gamma; const float* pro_beta; const float* pro_alpha; float* pro_ms_out;
+    const float* epi_alpha; double* epi_part;   // [M, H, 2]
+};
+
+template <bool PRO, bool EPI>
+__global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float buf[ROWS][FWD_BUF];
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = (a.H + ROWS - 1) / ROWS;
+    const int m = blockIdx.x / hb;
+    const int c = (blockIdx.x % hb) * ROWS + wave;
+    const bool live = c < a.H;
+    const size_t row = ((size_t)m * a.H + (live ? c : 0)) * a.Kp;
+    const float* __restrict__ y = a.Y + row;
+    float* __restrict__ z = a.Z + row;
+    float* __restrict__ L = buf[wave];
+
+    float mean = 0.f, rstd = 1.f, alpha = 0.f, g = 1.f, b = 0.f;
+    if constexpr (PRO) {
+        finalize_stats<NT>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts, (double)a.H * (double)a.K, red,
+                           mean, rstd);
+        alpha = a.pro_alpha[0];
+        if (live) { g = a.pro_gamma[c]; b = a.pro_beta[c]; }
+        if (a.pro_ms_out != nullptr && (blockIdx.x % hb) == 0 && tid == 0) {
+            a.pro_ms_out[2 * m] = mean;
+            a.pro_ms_out[2 * m + 1] = rstd;
+        }
+    }
+    float taps[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) taps[j] = (live && j < a.P) ? a.D[(size_t)c * a.P + j] : 0.f;
+    float e_alpha = 0.f;
+    if constexpr (EPI) e_alpha = a.epi_alpha[0];
+    const int halo = (a.P - 1) * a.dil;
+    float s1 = 0.f, s2 = 0.f;
+
+    for (int k0 = 0; k0 < a.Kp; k0 += a.seg) {
+        const int kend = min(k0 + a.seg, a.Kp);
+        const int base = floor4(k0 - a.padl);
+        const int nfill = (kend - k0) + halo + 4;           // covers idx up to (kend-1-base-padl)+halo
+        for (int j = lane * 4; j < nfill; j += 256) {
+            const int k = base + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && k >= 0 && k < a.Kp) {
+                v = ld4(y + k);
+                if constexpr (PRO) {
+                    v.x = (k + 0 < a.K) ? g * ((prelu_f(v.x, alpha) - mean) * rstd) + b : 0.f;
+                    v.y = (k + 1 < a.K) ? g * ((prelu_f(v.y, alpha) - mean) * rstd) + b : 0.f;
+                    v.z = (k + 2 < a.K) ? g * ((prelu_f(v.z, alpha) - mean) * rstd) + b : 0.f;
+                    v.w = (k + 3 < a.K) ? g * ((prelu_f(v.w, alpha) - mean) * rstd) + b : 0.f;
+                }
+            }
+            *reinterpret_cast<float4*>(L + j) = v;
+        }
+        __syncthreads();
+        for (int k = k0 + lane; k < kend; k += 64) {
+            const int idx = k - base - a.padl;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j)
+                if (j < a.P) acc += taps[j] * L[idx + j * a.dil];
+            if (k >= a.K) acc = 0.f;
+            if constexpr (EPI) {
+                const float p = prelu_f(acc, e_alpha);
+                s1 += p;
+                s2 += p * p;
+            }
+            if (live) z[k] = acc;
+        }
+        __syncthreads();
+    }
+    if constexpr (EPI) {
+        const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+        if (live && lane == 0) {
+            double* dst = a.epi_part + ((size_t)m * a.H + c) * 2;
+            dst[0] = d1;
+            dst[1] = d2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// depthwise backward.
+//   FUSED: given dN2 (grad of the 2nd norm's output), d (= dw output, pre-PReLU) and h1
+//          (= first 1x1 output, pre-PReLU):
+//            xh2 = (prelu(d)-mean2)*rstd2 ; da2 = rstd2*(g2*dN2 - S1/n - xh2*S2/n) ; dd = da2*prelu'(d)
+//            n1  = g1*xh1+b1, xh1 = (prelu(h1)-mean1)*rstd1
+//            dN1[k] = sum_j D[j]*dd[k - j*dil + padl] ;  dD[j] = sum_k dd[k]*n1[k + j*dil - padl]
+//          plus every per-channel / per-utterance sum the two norms and PReLUs need.
+//   PLAIN: dd = dZ, n1 = X as stored.
+// per-row float outputs pc[f][m][c]:  f = 0..P-1: dD ; FUSED adds P: dgamma2, P+1: dbeta2,
+//   P+2: dgamma1, P+3: dbeta1, P+4: dalpha2
+// ---------------------------------------------------------------------------
+struct DwBwdArgs {
+    const float* dN2; const float* Dz; const float* Y1; float* dN1; const float* D;
+    int M, H, K, Kp, P, dil, padl, seg;
+    const float* g1; const float* b1; const float* a1; const float* ms1;
+    const float* g2; const float* a2; const float* ms2;
+    const double* sums2_part; int sums2_nparts;
+    float* pc;             // [F, M, H]
+    double* sums1_part;    // [M, H, 2]
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float bufA[ROWS][BWD_BUF];  // dd
+    __shared__ __attribute__((aligned(16))) float bufB[ROWS][BWD_BUF];  // xh1 (FUSED) or x (PLAIN)
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = (a.H + ROWS - 1) / ROWS;
+    const int m = blockIdx.x / hb;
+    const int c = (blockIdx.x % hb) * ROWS + wave;
+    const bool live = c < a.H;
+    const size_t row = ((size_t)m * a.H + (live ? c : 0)) * a.Kp;
+    const float* __restrict__ dn2 = a.dN2 + row;
+    const float* __restrict__ dz = FUSED ? a.Dz + row : nullptr;
+    const float* __restrict__ y1 = a.Y1 + row;
+    float* __restrict__ dn1 = a.dN1 + row;
+    float* __restrict__ LA = bufA[wave];
+    float* __restrict__ LB = bufB[wave];
+
+    float mean1 = 0.f, rstd1 = 1.f, mean2 = 0.f, rstd2 = 1.f, al1 = 0.f, al2 = 0.f;
+    float g1 = 1.f, b1 = 0.f, g2 = 1.f, c1 = 0.f, c2 = 0.f;
+    if constexpr (FUSED) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int i = tid; i < a.sums2_nparts; i += NT) {
+            S1 += a.sums2_part[((size_t)m * a.sums2_nparts + i) * 2];
+            S2 += a.sums2_part[((size_t)m * a.sums2_nparts + i) * 2 + 1];
+        }
+        S1 = block_sum<double, NT>(S1, red);
+        S2 = block_sum<double, NT>(S2, red);
+        const double n = (double)a.H * (double)a.K;
+        c1 = (float)(S1 / n);
+        c2 = (float)(S2 / n);
+        mean1 = a.ms1[2 * m]; rstd1 = a.ms1[2 * m + 1];
+        mean2 = a.ms2[2 * m]; rstd2 = a.ms2[2 * m + 1];
+        al1 = a.a1[0]; al2 = a.a2[0];
+        if (live) { g1 = a.g1[c]; b1 = a.b1[c]; g2 = a.g2[c]; }
+    }
+    float taps[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) taps[j] = (live && j < a.P) ? a.D[(size_t)c * a.P + j] : 0.f;
+    const int halo = (a.P - 1) * a.dil;
+
+    float dD[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) dD[j] = 0.f;
+    float dg2 = 0.f, db2 = 0.f, dal2 = 0.f, dg1 = 0.f, db1 = 0.f, t1 = 0.f, t2 = 0.f;
+
+    for (int k0 = 0; k0 < a.Kp; k0 += a.seg) {
+        const int kend = min(k0 + a.seg, a.Kp);
+        // dd is needed on [k0 + padl - halo, kend-1 + padl]; x on [k0 - padl, kend-1 - padl + halo]
+        const int baseA = floor4(k0 + a.padl - halo);
+        const int baseB = floor4(k0 - a.padl);
+        const int nfill = (kend - k0) + halo + 4;
+        for (int j = lane * 4; j < nfill; j += 256) {
+            {
+                const int k = baseA + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && k >= 0 && k < a.Kp) {
+                    v = ld4(dn2 + k);
+                    if constexpr (FUSED) {
+                        const float4 d = ld4(dz + k);
+                        float vv[4] = {v.x, v.y, v.z, v.w};
+                        const float dd_[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool valid = (k + e) < a.K;
+                            const float xh = (prelu_f(dd_[e], al2) - mean2) * rstd2;
+                            const float da = rstd2 * (g2 * vv[e] - c1 - xh * c2);
+                            const bool own = valid && (k + e) >= k0 && (k + e) < kend;   // count each frame once
+                            if (own) {
+                                dg2 += vv[e] * xh;
+                                db2 += vv[e];
+                                if (dd_[e] < 0.f) dal2 += da * dd_[e];
+                            }
+                            vv[e] = valid ? (dd_[e] >= 0.f ? da : al2 * da) : 0.f;
+                        }
+                        v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                }
+                *reinterpret_cast<float4*>(LA + j) = v;
+            }
+            {
+                const int k = baseB + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && k >= 0 && k < a.Kp) {
+                    v = ld4(y1 + k);
+                    if constexpr (FUSED) {
+                        v.x = (prelu_f(v.x, al1) - mean1) * rstd1;
+                        v.y = (prelu_f(v.y, al1) - mean1) * rstd1;
+                        v.z = (prelu_f(v.z, al1) - mean1) * rstd1;
+                        v.w = (prelu_f(v.w, al1) - mean1) * rstd1;
+                    }
+                }
+                *reinterpret_cast<float4*>(LB + j) = v;
+            }
+        }
+        __syncthreads();
+        for (int k = k0 + lane; k < kend; k += 64) {
+            // input gradient: transposed taps
+            float acc = 0.f;
+            const int ia = k + a.padl - baseA;
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j)
+                if (j < a.P) acc += taps[j] * LA[ia - j * a.dil];
+            if (k >= a.K) acc = 0.f;
+            // tap gradients
+            const float ddk = LA[k - baseA];
+            const int ib = k - a.padl - baseB;
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j)
+                if (j < a.P) {
+                    const int kk = k - a.padl + j * a.dil;
+                    float xv = LB[ib + j * a.dil];
+                    if constexpr (FUSED) xv = (kk >= 0 && kk < a.K) ? g1 * xv + b1 : 0.f;
+                    dD[j] += ddk * xv;
+                }
+            if constexpr (FUSED) {
+                if (k < a.K) {
+                    const float xh1 = LB[k - baseB];
+                    dg1 += acc * xh1;
+                    db1 += acc;
+                    const float t = g1 * acc;
+                    t1 += t;
+                    t2 += t * xh1;
+                }
+            }
+            if (live) dn1[k] = acc;
+        }
+        __syncthreads();
+    }
+    const size_t MH = (size_t)a.M * a.H, rc = (size_t)m * a.H + c;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j)
+        if (j < a.P) {
+            const float v = wave_sum(dD[j]);
+            if (live && lane == 0) a.pc[(size_t)j * MH + rc] = v;
+        }
+    if constexpr (FUSED) {
+        const float v0 = wave_sum(dg2), v1 = wave_sum(db2), v2 = wave_sum(dg1), v3 = wave_sum(db1), v4 = wave_sum(dal2);
+        const double w1 = wave_sum((double)t1), w2 = wave_sum((double)t2);
+        if (live && lane == 0) {
+            a.pc[(size_t)(a.P + 0) * MH + rc] = v0;
+            a.pc[(size_t)(a.P + 1) * MH + rc] = v1;
+            a.pc[(size_t)(a.P + 2) * MH + rc] = v2;
+            a.pc[(size_t)(a.P + 3) * MH + rc] = v3;
+            a.pc[(size_t)(a.P + 4) * MH + rc] = v4;
+            a.sums1_part[rc * 2] = w1;
+            a.sums1_part[rc * 2 + 1] = w2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dY = rstd*(g*dN - S1/n - xh*S2/n) * prelu'(y),  xh = (prelu(y)-mean)*rstd ; dalpha partial per row
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restrict__ dN, const float* __restrict__ Y,
+                                                           float* __restrict__ dY, int M, int H, int K, int Kp,
+                                                           const float* __restrict__ gamma, const float* __restrict__ alpha_p,
+                                                           const float* __restrict__ ms, const double* __restrict__ sums_part,
+                                                           int nparts, float* __restrict__ dalpha_part) {
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = (H + ROWS - 1) / ROWS;
+    const int m = blockIdx.x / hb;
+    const int c = (blockIdx.x % hb) * ROWS + wave;
+    double S1 = 0.0, S2 = 0.0;
+    for (int i = tid; i < nparts; i += NT) {
+        S1 += sums_part[((size_t)m * nparts + i) * 2];
+        S2 += sums_part[((size_t)m * nparts + i) * 2 + 1];
+    }
+    S1 = block_sum<double, NT>(S1, red);
+    S2 = block_sum<double, NT>(S2, red);
+    if (c >= H) return;
+    const double n = (double)H * (double)K;
+    const float c1 = (float)(S1 / n), c2 = (float)(S2 / n);
+    const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha_p[0], g = gamma[c];
+    const size_t row = ((size_t)m * H + c) * Kp;
+    float dal = 0.f;
+    for (int k = lane * 4; k < Kp; k += 256) {
+        const float4 dn = ld4(dN + row + k);
+        const float4 y = ld4(Y + row + k);
+        const float dv[4] = {dn.x, dn.y, dn.z, dn.w};
+        const float yv[4] = {y.x, y.y, y.z, y.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (prelu_f(yv[e], al) - mean) * rstd;
+            const float da = rstd * (g * dv[e] - c1 - xh * c2);
+            const bool valid = (k + e) < K;
+            if (valid && yv[e] < 0.f) dal += da * yv[e];
+            o[e] = valid ? (yv[e] >= 0.f ? da : al * da) : 0.f;
+        }
+        *reinterpret_cast<float4*>(dY + row + k) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    dal = wave_sum(dal);
+    if (lane == 0) dalpha_part[(size_t)m * H + c] = dal;
+}
+
+// ---------------------------------------------------------------------------
+// channel-wise LayerNorm (optionally after PReLU), per (m, frame) over channels.
+// block = 64 frames x 4 channel-groups (one wave each).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void cln_fwd_kernel(const float* __restrict__ Y, float* __restrict__ Out,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     int M, int Ch, int K, int Kp, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ alpha_p) {
+    __shared__ float sh[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kb = (Kp + 63) / 64;
+    const int m = blockIdx.x / kb, k = (blockIdx.x % kb) * 64 + lane;
+    const bool in = k < Kp;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const float* __restrict__ y = Y + (size_t)m * Ch * Kp + (in ? k : 0);
+    float s = 0.f;
+    for (int c = wave; c < Ch; c += 4) {
+        float v = in ? y[(size_t)c * Kp] : 0.f;
+        if (has_a) v = prelu_f(v, al);
+        s += v;
+    }
+    sh[wave][lane] = s;
+    __syncthreads();
+    const float mu = (sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]) / (float)Ch;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = wave; c < Ch; c += 4) {
+        float v = in ? y[(size_t)c * Kp] : 0.f;
+        if (has_a) v = prelu_f(v, al);
+        q += (v - mu) * (v - mu);
+    }
+    sh[wave][lane] = q;
+    __syncthreads();
+    const float var = (sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane]) / (float)Ch;
+    const float rs = 1.0f / sqrtf(var + CTN_EPS);
+    if (wave == 0 && in) {
+        mean_o[(size_t)m * Kp + k] = mu;
+        rstd_o[(size_t)m * Kp + k] = rs;
+    }
+    if (!in) return;
+    float* __restrict__ o = Out + (size_t)m * Ch * Kp + k;
+    const bool valid = k < K;
+    for (int c = wave; c < Ch; c += 4) {
+        float v = y[(size_t)c * Kp];
+        if (has_a) v = prelu_f(v, al);
+        o[(size_t)c * Kp] = valid ? gamma[c] * ((v - mu) * rs) + beta[c] : 0.f;
+    }
+}
+
+// dY = [ rstd*(t - mean_c(t) - xh*mean_c(t*xh)) * prelu'(y) + add ] * (relu_ref > 0)
+__global__ __launch_bounds__(NT) void cln_bwd_dx_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                        float* __restrict__ dY, const float* __restrict__ mean_i,
+                                                        const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
+                                                        const float* __restrict__ gamma, const float* __restrict__ alpha_p,
+                                                        const float* __restrict__ add, const float* __restrict__ relu_ref,
+                                                        float* __restrict__ dalpha_part) {
+    __shared__ float sh[2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kb = (Kp + 63) / 64;
+    const int m = blockIdx.x / kb, k = (blockIdx.x % kb) * 64 + lane;
+    const bool in = k < Kp, valid = k < K;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const size_t off = (size_t)m * Ch * Kp + (in ? k : 0);
+    const float mu = in ? mean_i[(size_t)m * Kp + k] : 0.f, rs = in ? rstd_i[(size_t)m * Kp + k] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = wave; c < Ch; c += 4) {
+        if (valid) {
+            float v = Y[off + (size_t)c * Kp];
+            if (has_a) v = prelu_f(v, al);
+            const float t = gamma[c] * dOut[off + (size_t)c * Kp];
+            s1 += t;
+            s2 += t * ((v - mu) * rs);
+        }
+    }
+    sh[0][wave][lane] = s1;
+    sh[1][wave][lane] = s2;
+    __syncthreads();
+    const float m1 = (sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane]) / (float)Ch;
+    const float m2 = (sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane]) / (float)Ch;
+    float dal = 0.f;
+    if (in) {
+        for (int c = wave; c < Ch; c += 4) {
+            const size_t o = off + (size_t)c * Kp;
+            float r = 0.f;
+            if (valid) {
+                const float yv = Y[o];
+                const float v = has_a ? prelu_f(yv, al) : yv;
+                const float xh = (v - mu) * rs;
+                const float da = rs * (gamma[c] * dOut[o] - m1 - xh * m2);
+                if (has_a && yv < 0.f) dal += da * yv;
+                r = (has_a && yv < 0.f) ? al * da : da;
+                if (add != nullptr) r += add[o];
+                if (relu_ref != nullptr && !(relu_ref[o] > 0.f)) r = 0.f;
+            }
+            dY[o] = r;
+        }
+    }
+    if (dalpha_part != nullptr) {
+        __syncthreads();
+        dal = wave_sum(dal);
+        if (lane == 0) sh[0][wave][0] = dal;
+        __syncthreads();
+        if (tid == 0) dalpha_part[blockIdx.x] = sh[0][0][0] + sh[0][1][0] + sh[0][2][0] + sh[0][3][0];
+    }
+}
+
+// per-(m,c) partial of dgamma = sum_k dOut*xh and dbeta = sum_k dOut ; pc[2][M][Ch]
+__global__ __launch_bounds__(NT) void cln_bwd_params_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                            int M, int Ch, int K, int Kp, const float* __restrict__ alpha_p,
+                                                            float* __restrict__ pc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = (Ch + ROWS - 1) / ROWS;
+    const int m = blockIdx.x / hb;
+    const int c = (blockIdx.x % hb) * ROWS + wave;
+    if (c >= Ch) return;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const size_t row = ((size_t)m * Ch + c) * Kp;
+    float dg = 0.f, db = 0.f;
+    for (int k = lane * 4; k < Kp; k += 256) {
+        const float4 d = ld4(dOut + row + k), y = ld4(Y + row + k);
+        const float4 mu = ld4(mean_i + (size_t)m * Kp + k), rs = ld4(rstd_i + (size_t)m * Kp + k);
+        const float dv[4] = {d.x, d.y, d.z, d.w}, yv[4] = {y.x, y.y, y.z, y.w};
+        const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, rv[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k + e < K) {
+                const float v = has_a ? prelu_f(yv[e], al) : yv[e];
+                dg += dv[e] * ((v - mv[e]) * rv[e]);
+                db += dv[e];
+            }
+    }
+    dg = wave_sum(dg);
+    db = wave_sum(db);
+    if (lane == 0) {
+        pc[(size_t)m * Ch + c] = dg;
+        pc[(size_t)M * Ch + (size_t)m * Ch + c] = db;
+    }
+}
+
+// out[f][i] = sum_mid in[f][mid][i]   (fixed order).  mode 0: thread per output; mode 1: wave per output.
+__global__ __launch_bounds__(NT) void reduce_mid_kernel(const float* __restrict__ in, int F, int Mid, int Inner,
+                                                        float* __restrict__ out, int wave_mode) {
+    if (!wave_mode) {
+        const long long o = (long long)blockIdx.x * NT + threadIdx.x;
+        if (o >= (long long)F * Inner) return;
+        const int f = (int)(o / Inner), i = (int)(o % Inner);
+        float s = 0.f;
+        for (int r = 0; r < Mid; ++r) s += in[((size_t)f * Mid + r) * Inner + i];
+        out[o] = s;
+    } else {
+        const long long o = (long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+        if (o >= (long long)F * Inner) return;
+        const int f = (int)(o / Inner), i = (int)(o % Inner), lane = threadIdx.x & 63;
+        float s = 0.f;
+        for (int r = lane; r < Mid; r += 64) s += in[((size_t)f * Mid + r) * Inner + i];
+        s = wave_sum(s);
+        if (lane == 0) out[o] = s;
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
+               const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+               const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, void* stream) {
+    CTN_REQUIRE(Y && Z && D, "ctn_dw_fwd: null pointer");
+    CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_dw_fwd: bad sizes");
+    CTN_REQUIRE(P >= 1 && P <= MAXP && dilation >= 1, "ctn_dw_fwd: kernel size %d unsupported (max %d)", P, MAXP);
+    CTN_REQUIRE(aligned16(Y) && aligned16(Z), "ctn_dw_fwd: pointers must be 16-byte aligned");
+    const int halo = (P - 1) * dilation;
+    CTN_REQUIRE(causal || halo % 2 == 0, "ctn_dw_fwd: non-causal 'same' padding needs (P-1)*dilation even");
+    const int seg = ((FWD_BUF - halo - 8) / 64) * 64;
+    CTN_REQUIRE(seg >= 64, "ctn_dw_fwd: receptive field (P-1)*dilation=%d too large", halo);
+    CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0), "ctn_dw_fwd: incomplete prologue arguments");
+    CTN_REQUIRE(!epi_part || epi_alpha, "ctn_dw_fwd: stats epilogue needs alpha");
+    DwFwdArgs a{};
+    a.Y = Y; a.Z = Z; a.D = D; a.M = M; a.H = H; a.K = K; a.Kp = Kp; a.P = P; a.dil = dilation;
+    a.padl = causal ? halo : halo / 2; a.seg = seg;
+    a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
+    a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
+    const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
+    hipStream_t st = (hipStream_t)stream;
+    if (pro_part && epi_part) hipLaunchKernelGGL((dw_fwd_kernel<true, true>), grid, block, 0, st, a);
+    else if (pro_part) hipLaunchKernelGGL((dw_fwd_kernel<true, false>), grid, block, 0, st, a);
+    else if (epi_part) hipLaunchKernelGGL((dw_fwd_kernel<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((dw_fwd_kernel<false, false>), grid, block, 0, st, a);
+    CTN_CHECK_LAUNCH("ctn_dw_fwd");
+    return CTN_OK;
+}
+
+int ctn_dw_bwd_rows(int P, int fused) { return fused ? P + 5 : P; }
+
+// see include/ctn_hip.h.  pc is [F, M, H] with F = ctn_dw_bwd_rows(P, fused)
+int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, const float* D,
+               int M, int H, int K, int Kp, int P, int dilation, int causal, int fused,
+               const float* g1, const float* b1, const float* a1, const float* ms1,
+               const float* g2, const float* a2, const float* ms2,
+               const double* sums2_part, int sums2_nparts, float* pc, double* sums1_part, void* stream) {
+    CTN_REQUIRE(dN2 && Y1 && dN1 && D && pc, "ctn_dw_bwd: null pointer");
+    CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_dw_bwd: bad sizes");
+    CTN_REQUIRE(P >= 1 && P <= MAXP && dilation >= 1, "ctn_dw_bwd: kernel size %d unsupported (max %d)", P, MAXP);
+    CTN_REQUIRE(aligned16(dN2) && aligned16(Y1) && aligned16(dN1) && (!fused || aligned16(Dz)), "ctn_dw_bwd: alignment");
+    const int halo = (P - 1) * dilation;
+    CTN_REQUIRE(causal || halo % 2 == 0, "ctn_dw_bwd: non-causal 'same' padding needs (P-1)*dilation even");
+    const int seg = ((BWD_BUF - halo - 8) / 64) * 64;
+    CTN_REQUIRE(seg >= 64, "ctn_dw_bwd: receptive field (P-1)*dilation=%d too large", halo);
+    if (fused)
+        CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && sums1_part,
+                    "ctn_dw_bwd: fused mode needs every norm argument");
+    DwBwdArgs a{};
+    a.dN2 = dN2; a.Dz = Dz; a.Y1 = Y1; a.dN1 = dN1; a.D = D;
+    a.M = M; a.H = H; a.K = K; a.Kp = Kp; a.P = P; a.dil = dilation; a.padl = causal ? halo : halo / 2; a.seg = seg;
+    a.g1 = g1; a.b1 = b1; a.a1 = a1; a.ms1 = ms1; a.g2 = g2; a.a2 = a2; a.ms2 = ms2;
+    a.sums2_part = sums2_part; a.sums2_nparts = sums2_nparts; a.pc = pc; a.sums1_part = sums1_part;
+    const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
+    if (fused) hipLaunchKernelGGL((dw_bwd_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dw_bwd_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
+    CTN_CHECK_LAUNCH("ctn_dw_bwd");
+    return CTN_OK;
+}
+
+int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
+                      const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
+                      float* dalpha_part, void* stream) {
+    CTN_REQUIRE(dN && Y && dY && gamma && alpha && ms && sums_part && dalpha_part && nparts > 0, "ctn_gln_prelu_bwd: null pointer");
+    CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_gln_prelu_bwd: bad sizes");
+    CTN_REQUIRE(aligned16(dN) && aligned16(Y) && aligned16(dY), "ctn_gln_prelu_bwd: alignment");
+    hipLaunchKernelGGL(gln_prelu_bwd_kernel, dim3((unsigned)(M * ctn_cdiv(H, ROWS))), dim3(NT), 0, (hipStream_t)stream,
+                       dN, Y, dY, M, H, K, Kp, gamma, alpha, ms, sums_part, nparts, dalpha_part);
+    CTN_CHECK_LAUNCH("ctn_gln_prelu_bwd");
+    return CTN_OK;
+}
+
+int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int Ch, int K, int Kp,
+                const float* gamma, const float* beta, const float* alpha, void* stream) {
+    CTN_REQUIRE(Y && Out && mean && rstd && gamma && beta, "ctn_cln_fwd: null pointer");
+    CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K, "ctn_cln_fwd: bad sizes");
+    hipLaunchKernelGGL(cln_fwd_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, (hipStream_t)stream,
+                       Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha);
+    CTN_CHECK_LAUNCH("ctn_cln_fwd");
+    return CTN_OK;
+}
+
+int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, 64); }
+
+// dalpha_part: [ctn_cln_bwd_blocks] (only when alpha != NULL); pc: [2, M, Ch]
+int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
+                int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
+                const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream) {
+    CTN_REQUIRE(dOut && Y && dY && mean && rstd && gamma && pc, "ctn_cln_bwd: null pointer");
+    CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_cln_bwd: bad sizes");
+    CTN_REQUIRE(!alpha || dalpha_part, "ctn_cln_bwd: dalpha_part required with alpha");
+    CTN_REQUIRE(aligned16(dOut) && aligned16(Y) && aligned16(mean) && aligned16(rstd), "ctn_cln_bwd: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    // parameter partials first: dY may alias dOut
+    hipLaunchKernelGGL(cln_bwd_params_kernel, dim3((unsigned)(M * ctn_cdiv(Ch, ROWS))), dim3(NT), 0, st,
+                       dOut, Y, mean, rstd, M, Ch, K, Kp, alpha, pc);
+    CTN_CHECK_LAUNCH("ctn_cln_bwd/params");
+    hipLaunchKernelGGL(cln_bwd_dx_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st,
+                       dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, alpha ? dalpha_part : nullptr);
+    CTN_CHECK_LAUNCH("ctn_cln_bwd/dx");
+    return CTN_OK;
+}
+
+// out[f][i] = sum_r in[f][r][i]
+int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void* stream) {
+    CTN_REQUIRE(in && out && F > 0 && Mid > 0 && Inner > 0, "ctn_reduce_mid: bad arguments");
+    const long long n = (long long)F * Inner;
+    const int wave_mode = (Mid >= 256 && n <= 4096) ? 1 : 0;
+    const unsigned blocks = wave_mode ? (unsigned)ctn_cdivll(n, NT / 64) : (unsigned)ctn_cdivll(n, NT);
+    hipLaunchKernelGGL(reduce_mid_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, in, F, Mid, Inner, out, wave_mode);
+    CTN_CHECK_LAUNCH("ctn_reduce_mid");
+    return CTN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+"""torch.autograd glue over the C ABI (include/ctn_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams and records which stage's
+backward runs when.  Every FLOP of the hot path is a hand-written gfx950 kernel behind
+``lib.call``; there is no eager fallback (a missing library or a CPU tensor raises).
+
+Internal activation format: fp32 ``[M, Ch, Kp]`` with ``Kp = padded_frames(K)`` and exact
+zeros in columns ``k >= K`` (see the header).  The stage functions below each cover one
+autograd node:
+
+  Frontend : encoder conv + ReLU -> input cLN -> bottleneck 1x1   (src/conv_tasnet.py:108-121,172-174)
+  GlnBlock : TemporalBlock with gLN, fully fused                  (src/conv_tasnet.py:218-278)
+  ClnBlock : TemporalBlock with cLN (causal variant)              (same, norm_type='cLN')
+  Backend  : mask 1x1 -> relu|softmax -> mask*w -> basis -> OLA   (src/conv_tasnet.py:191,206-215,131-146)
+  SiSnrPit : PIT SI-SNR loss                                      (src/pit_criterion.py:12-77)
+"""
+import itertools
+
+import torch
+
+from ._lib import lib, CtnError
+
+F32 = torch.float32
+F64 = torch.float64
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CtnError("the HIP path needs tensors on the GPU (got a CPU tensor); there is no CPU fallback")
+        if t.dtype not in (F32, F64, torch.int64, torch.int32):
+            raise CtnError("unsupported dtype %s" % t.dtype)
+        if not t.is_contiguous():
+            raise CtnError("internal error: non-contiguous tensor reached the C ABI")
+
+
+def padded_frames(K):
+    return lib.ctn_padded_frames(int(K))
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# thin typed wrappers (one per entry point actually used below)
+# ---------------------------------------------------------------------------------------
+def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=None, relu_out=False, ms_out=None):
+    """Out[M,R,Kp] = op(W) . f(X).  pro = (part[M,np,2] f64, gamma, beta, alpha).  Returns (Out, epi_part|None)."""
+    M, _, Kp = X.shape
+    out = torch.empty((M, R, Kp), dtype=F32, device=X.device)
+    epi_part = None
+    if epi_alpha is not None:
+        epi_part = torch.empty((M, lib.ctn_pw_stats_parts(R, Kp), 2), dtype=F64, device=X.device)
+    pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
+    _chk(W, X, pp, pg, pb, pa, residual, epi_alpha, ms_out)
+    lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, int(trans_w),
+             _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
+             int(relu_out), _stream())
+    return out, epi_part
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    """Scratch that is fully consumed inside one C call (stream-ordered), so one buffer per tag is enough."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def pw_wgrad(dOut, X, R, Cn, K, pro=None):
+    """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2])."""
+    M, _, Kp = X.shape
+    dW = torch.empty((R, Cn), dtype=F32, device=X.device)
+    nbytes = lib.ctn_pw_wgrad_workspace(M, R, Cn, Kp)
+    ws = _workspace(nbytes, X.device, "wgrad")
+    pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
+    _chk(dOut, X, pg, pb, pa, pms)
+    lib.call("ctn_pw_wgrad", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb), _p(pa), _p(pms),
+             _p(ws), nbytes, _stream())
+    return dW
+
+
+def reduce_mid(x, F, Mid, Inner):
+    out = torch.empty((F, Inner), dtype=F32, device=x.device)
+    _chk(x)
+    lib.call("ctn_reduce_mid", _p(x), _p(out), F, Mid, Inner, _stream())
+    return out
+
+
+def cln_fwd(Y, gamma, beta, alpha, K):
+    M, Ch, Kp = Y.shape
+    out = torch.empty_like(Y)
+    mean = torch.empty((M, Kp), dtype=F32, device=Y.device)
+    rstd = torch.empty((M, Kp), dtype=F32, device=Y.device)
+    _chk(Y, gamma, beta, alpha)
+    lib.call("ctn_cln_fwd", _p(Y), _p(out), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(beta), _p(alpha), _stream())
+    return out, mean, rstd
+
+
+def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None):
+    """-> dY, dgamma[Ch], dbeta[Ch], dalpha[1]|None"""
+    M, Ch, Kp = Y.shape
+    dY = torch.empty_like(Y)
+    pc = torch.empty((2, M, Ch), dtype=F32, device=Y.device)
+    dap = None
+    if alpha is not None:
+        dap = torch.empty((lib.ctn_cln_bwd_blocks(M, Kp),), dtype=F32, device=Y.device)
+    _chk(dOut, Y, mean, rstd, gamma, alpha, add, relu_ref)
+    lib.call("ctn_cln_bwd", _p(dOut), _p(Y), _p(dY), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(alpha),
+             _p(add), _p(relu_ref), _p(dap), _p(pc), _stream())
+    red = reduce_mid(pc, 2, M, Ch)
+    dalpha = None if dap is None else reduce_mid(dap, 1, dap.numel(), 1).view(1)
+    return dY, red[0], red[1], dalpha
+
+
+def dw_fwd(Y, D, K, dilation, causal, pro=None, epi_alpha=None, ms_out=None):
+    M, H, Kp = Y.shape
+    P = D.shape[-1]
+    Z = torch.empty_like(Y)
+    epi_part = None if epi_alpha is None else torch.empty((M, H, 2), dtype=F64, device=Y.device)
+    pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
+    _chk(Y, D, pp, pg, pb, pa, epi_alpha, ms_out)
+    lib.call("ctn_dw_fwd", _p(Y), _p(Z), _p(D), M, H, K, Kp, P, dilation, int(causal),
+             _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(epi_alpha), _p(epi_part), _stream())
+    return Z, epi_part
+
+
+# ---------------------------------------------------------------------------------------
+# Frontend: mixture -> (mixture_w, bottleneck output)
+# ---------------------------------------------------------------------------------------
+class Frontend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mix, U, g0, b0, Wb):
+        M, T = mix.shape
+        N, _, L = U.shape
+        B = Wb.shape[0]
+        if L % 4 or N % 4 or B % 4:
+            raise ValueError("HIP path needs L, N, B to be multiples of 4 (got L=%d N=%d B=%d)" % (L, N, B))
+        S = L // 2
+        K = (T - L) // S + 1
+        Kp = padded_frames(K)
+        mix = _c(mix)
+        xcol = torch.empty((M, L, Kp), dtype=F32, device=mix.device)
+        _chk(mix, U, g0, b0, Wb)
+        lib.call("ctn_im2col", _p(mix), _p(xcol), M, T, L, L, K, Kp, _stream())
+        w, _ = pw_gemm(U, xcol, N, L, K, relu_out=True)
+        y0, mean0, rstd0 = cln_fwd(w, g0, b0, None, K)
+        x0, _ = pw_gemm(Wb, y0, B, N, K)
+        ctx.save_for_backward(xcol, w, y0, mean0, rstd0, U, g0, Wb)
+        ctx.K = K
+        ctx.set_materialize_grads(False)
+        return w, x0
+
+    @staticmethod
+    def backward(ctx, dw_dec, dx0):
+        xcol, w, y0, mean0, rstd0, U, g0, Wb = ctx.saved_tensors
+        K = ctx.K
+        M, N, Kp = w.shape
+        B = Wb.shape[0]
+        L = U.shape[-1]
+        if dx0 is None:
+            dx0 = torch.zeros((M, B, Kp), dtype=F32, device=w.device)
+        dx0 = _c(dx0)
+        dy0, _ = pw_gemm(Wb, dx0, N, B, K, trans_w=True)
+        dWb = pw_wgrad(dx0, y0, B, N, K)
+        add = None if dw_dec is None else _c(dw_dec)
+        g, dg0, db0, _ = cln_bwd(dy0, w, mean0, rstd0, g0, None, K, add=add, relu_ref=w)
+        dU = pw_wgrad(g, xcol, N, L, K)
+        return None, dU.view(N, 1, L), dg0.view(1, N, 1), db0.view(1, N, 1), dWb.view(B, N, 1)
+
+
+# ---------------------------------------------------------------------------------------
+# TemporalBlock, gLN: 3 kernels forward, 6 (+3 tiny reductions) backward
+# ---------------------------------------------------------------------------------------
+class GlnBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, a1, g1, b1, D, a2, g2, b2, w2, K, dilation, causal):
+        x = _c(x)
+        M, B, Kp = x.shape
+        H = w1.shape[0]
+        if H % 4 or B % 4:
+            raise ValueError("HIP path needs B and H to be multiples of 4")
+        dev = x.device
+        h1, st1 = pw_gemm(w1, x, H, B, K, epi_alpha=a1)
+        ms1 = torch.empty((M, 2), dtype=F32, device=dev)
+        d, st2 = dw_fwd(h1, D, K, dilation, causal, pro=(st1, g1, b1, a1), epi_alpha=a2, ms_out=ms1)
+        ms2 = torch.empty((M, 2), dtype=F32, device=dev)
+        out, _ = pw_gemm(w2, d, B, H, K, pro=(st2, g2, b2, a2), residual=x, ms_out=ms2)
+        ctx.save_for_backward(x, h1, d, ms1, ms2, w1, a1, g1, b1, D, a2, g2, b2, w2)
+        ctx.cfg = (K, dilation, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, d, ms1, ms2, w1, a1, g1, b1, D, a2, g2, b2, w2 = ctx.saved_tensors
+        K, dilation, causal = ctx.cfg
+        dout = _c(dout)
+        M, B, Kp = x.shape
+        H = w1.shape[0]
+        P = D.shape[-1]
+        dev = x.device
+        st = _stream()
+        # -- second 1x1: input gradient (+ gLN2 backward sums) and weight gradient
+        np2 = lib.ctn_pw_stats_parts(H, Kp)
+        dn2 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+        s2p = torch.empty((M, np2, 2), dtype=F64, device=dev)
+        _chk(dout, x, h1, d)
+        lib.call("ctn_pw_dgrad_gln", _p(w2), _p(dout), _p(dn2), M, H, B, K, Kp, _p(d), _p(g2), _p(a2), _p(ms2), _p(s2p), st)
+        dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2))
+        # -- gLN2 <- PReLU2 <- depthwise <- gLN1 output, one pass
+        Fr = lib.ctn_dw_bwd_rows(P, 1)
+        pc = torch.empty((Fr, M, H), dtype=F32, device=dev)
+        s1p = torch.empty((M, H, 2), dtype=F64, device=dev)
+        dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+        lib.call("ctn_dw_bwd", _p(dn2), _p(d), _p(h1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 1,
+                 _p(g1), _p(b1), _p(a1), _p(ms1), _p(g2), _p(a2), _p(ms2), _p(s2p), np2, _p(pc), _p(s1p), st)
+        red = reduce_mid(pc, Fr, M, H)
+        dD = red[:P].t().contiguous().view(H, 1, P)
+        da2 = reduce_mid(red[P + 4], 1, H, 1).view(1)
+        # -- gLN1 + PReLU1 backward, in place on dn1
+        da1p = torch.empty((M * H,), dtype=F32, device=dev)
+        lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), st)
+        da1 = reduce_mid(da1p, 1, M * H, 1).view(1)
+        # -- first 1x1
+        dx, _ = pw_gemm(w1, dn1, B, H, K, trans_w=True, residual=dout)
+        dW1 = pw_wgrad(dn1, x, H, B, K)
+        return (dx, dW1.view(H, B, 1), da1, red[P + 2].view(1, H, 1), red[P + 3].view(1, H, 1), dD, da2,
+                red[P].view(1, H, 1), red[P + 1].view(1, H, 1), dW2.view(B, H, 1), None, None, None)
+
+
+# ---------------------------------------------------------------------------------------
+# TemporalBlock, cLN (causal config): unfused norm kernels around the same GEMMs / depthwise
+# ---------------------------------------------------------------------------------------
+class ClnBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, a1, g1, b1, D, a2, g2, b2, w2, K, dilation, causal):
+        x = _c(x)
+        M, B, Kp = x.shape
+        H = w1.shape[0]
+        if H % 4 or B % 4:
+            raise ValueError("HIP path needs B and H to be multiples of 4")
+        h1, _ = pw_gemm(w1, x, H, B, K)
+        n1, mean1, rstd1 = cln_fwd(h1, g1, b1, a1, K)
+        d, _ = dw_fwd(n1, D, K, dilation, causal)
+        n2, mean2, rstd2 = cln_fwd(d, g2, b2, a2, K)
+        out, _ = pw_gemm(w2, n2, B, H, K, residual=x)
+        ctx.save_for_backward(x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2)
+        ctx.cfg = (K, dilation, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2 = ctx.saved_tensors
+        K, dilation, causal = ctx.cfg
+        dout = _c(dout)
+        M, B, Kp = x.shape
+        H = w1.shape[0]
+        P = D.shape[-1]
+        dev = x.device
+        dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
+        dW2 = pw_wgrad(dout, n2, B, H, K)
+        dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K)
+        pc = torch.empty((P, M, H), dtype=F32, device=dev)
+        dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+        _chk(dd, n1)
+        lib.call("ctn_dw_bwd", _p(dd), 0, _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 0,
+                 0, 0, 0, 0, 0, 0, 0, 0, 0, _p(pc), 0, _stream())
+        dD = reduce_mid(pc, P, M, H).t().contiguous().view(H, 1, P)
+        dh1, dg1, db1, da1 = cln_bwd(dn1, h1, mean1, rstd1, g1, a1, K)
+        dx, _ = pw_gemm(w1, dh1, B, H, K, trans_w=True, residual=dout)
+        dW1 = pw_wgrad(dh1, x, H, B, K)
+        return (dx, dW1.view(H, B, 1), da1, dg1.view(1, H, 1), db1.view(1, H, 1), dD, da2,
+                dg2.view(1, H, 1), db2.view(1, H, 1), dW2.view(B, H, 1), None, None, None)
+
+
+# ---------------------------------------------------------------------------------------
+# Backend: (TCN output, mixture_w) -> estimated sources [M, C, T]
+# ---------------------------------------------------------------------------------------
+def _mask_scores(x, Wm, K):
+    CN, B = Wm.shape[0], Wm.shape[1]
+    score, _ = pw_gemm(Wm, x, CN, B, K)
+    return score
+
+
+def mask_apply(score, w, C, softmax):
+    M, N, Kp = w.shape
+    sw = torch.empty((M, C, N, Kp), dtype=F32, device=w.device)
+    _chk(score, w)
+    lib.call("ctn_mask_apply", _p(score), _p(w), _p(sw), M, C, N, Kp, int(softmax), _stream())
+    return sw
+
+
+class Backend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, Wm, V, K, T, C, softmax):
+        x, w = _c(x), _c(w)
+        M, N, Kp = w.shape
+        L = V.shape[0]
+        if L % 4 or N % 4:
+            raise ValueError("HIP path needs L and N to be multiples of 4")
+        score = _mask_scores(x, Wm, K)
+        sw = mask_apply(score, w, C, softmax)
+        fr, _ = pw_gemm(V, sw.view(M * C, N, Kp), L, N, K)
+        est = torch.empty((M, C, T), dtype=F32, device=w.device)
+        lib.call("ctn_ola", _p(fr), _p(est), M * C, T, L, L, K, Kp, _stream())
+        ctx.save_for_backward(x, w, score, sw, Wm, V)
+        ctx.cfg = (K, T, C, softmax)
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        x, w, score, sw, Wm, V = ctx.saved_tensors
+        K, T, C, softmax = ctx.cfg
+        dest = _c(dest)
+        M, N, Kp = w.shape
+        L = V.shape[0]
+        B = Wm.shape[1]
+        CN = C * N
+        dev = w.device
+        dfr = torch.empty((M * C, L, Kp), dtype=F32, device=dev)
+        _chk(dest)
+        lib.call("ctn_unfold", _p(dest), _p(dfr), M * C, T, L, L, K, Kp, _stream())
+        dsw, _ = pw_gemm(V, dfr, N, L, K, trans_w=True)                 # [M*C, N, Kp]
+        dV = pw_wgrad(dfr, sw.view(M * C, N, Kp), L, N, K)
+        dw = torch.empty((M, N, Kp), dtype=F32, device=dev)
+        lib.call("ctn_mask_apply_bwd", _p(dsw), _p(score), _p(w), _p(dsw), _p(dw), M, C, N, Kp, int(softmax), _stream())
+        dscore = dsw.view(M, CN, Kp)
+        dx, _ = pw_gemm(Wm, dscore, B, CN, K, trans_w=True)
+        dWm = pw_wgrad(dscore, x, CN, B, K)
+        return dx, dw, dWm.view(CN, B, 1), dV, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------
+# PIT SI-SNR loss
+# ---------------------------------------------------------------------------------------
+_perm_cache = {}
+
+
+def _perms(C, device):
+    key = (C, device)
+    if key not in _perm_cache:
+        p = list(itertools.permutations(range(C)))   # same order as src/pit_criterion.py:67
+        _perm_cache[key] = (torch.tensor(p, dtype=torch.int32, device=device),
+                            torch.tensor(p, dtype=torch.int64, device=device))
+    return _perm_cache[key]
+
+
+class SiSnrPit(torch.autograd.Function):
+    """(source, estimate, lengths) -> (loss[], max_snr[B,1], estimate masked in place, best perm index [B])."""
+
+    @staticmethod
+    def forward(ctx, source, estimate, lengths):
+        if source.shape != estimate.shape:
+            raise AssertionError("source and estimate_source must have the same size")   # src/pit_criterion.py:34
+        Bn, C, T = source.shape
+        source = _c(source.to(F32))
+        if not estimate.is_contiguous() or estimate.dtype != F32:
+            raise CtnError("estimate_source must be a contiguous fp32 tensor (it is masked in place)")
+        lengths = _c(lengths.to(device=source.device, dtype=torch.int64))
+        dev = source.device
+        p32, _ = _perms(C, dev)
+        max_snr = torch.empty((Bn, 1), dtype=F32, device=dev)
+        idx = torch.empty((Bn,), dtype=torch.int64, device=dev)
+        loss = torch.empty((), dtype=F32, device=dev)
+        coef = torch.empty((Bn, C, 4), dtype=F32, device=dev)
+        jsel = torch.empty((Bn, C), dtype=torch.int32, device=dev)
+        nbytes = lib.ctn_sisnr_workspace(Bn, C, T)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _chk(source, estimate, lengths)
+        lib.call("ctn_sisnr_pit_fwd", _p(source), _p(estimate), _p(lengths), _p(p32), p32.shape[0], Bn, C, T,
+                 _p(max_snr), _p(idx), _p(loss), 0, _p(coef), _p(jsel), _p(ws), nbytes, _stream())
+        ctx.mark_dirty(estimate)
+        ctx.mark_non_differentiable(idx)
+        ctx.save_for_backward(source, estimate, lengths, coef, jsel)
+        ctx.set_materialize_grads(False)
+        return loss, max_snr, estimate, idx
+
+    @staticmethod
+    def backward(ctx, g_loss, g_max, g_est, _g_idx):
+        source, estimate, lengths, coef, jsel = ctx.saved_tensors
+        Bn, C, T = source.shape
+        d_est = torch.empty_like(source)
+        g_loss = None if g_loss is None else _c(g_loss.to(F32))
+        g_max = None if g_max is None else _c(g_max.to(F32))
+        _chk(g_loss, g_max)
+        lib.call("ctn_sisnr_pit_bwd", _p(source), _p(estimate), _p(lengths), _p(coef), _p(jsel), _p(g_loss), _p(g_max),
+                 Bn, C, T, _p(d_est), _stream())
+        if g_est is not None:
+            t = torch.arange(T, device=source.device).view(1, 1, T)
+            d_est = d_est + g_est * (t < lengths.view(-1, 1, 1)).to(F32)
+        return None, d_est, None

@@ -1,0 +1,159 @@
+/* libctn_hip.so -- C ABI of the MI355X (gfx950) Conv-TasNet hot path.
+ *
+ * The reference (OfekCohen1/Conv-TasNet) has no FFI of its own: its hot path is torch.nn
+ * modules.  This header is the boundary a maintainer binds instead (ctypes
+ * stub in INTEGRATION.md); each entry point names the reference code it replaces, paths
+ * relative to the reference root.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory unless marked "host".
+ *  - the caller owns and allocates every buffer, workspaces included; the library never
+ *    allocates, frees or retains a pointer, and never synchronises the device.
+ *  - every launch goes to `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *  - return 0 on success, <0 on error (CTN_ERR_*); ctn_last_error() gives the message
+ *    for the calling thread.  Nothing throws across the boundary.
+ *  - activations are fp32 [M, Ch, Kp], frames fastest; Kp = ctn_padded_frames(K); columns
+ *    k in [K, Kp) hold exact zeros in every activation / gradient tensor (every kernel keeps
+ *    that invariant).  Channel counts must be multiples of 4; tensors 16-byte aligned.
+ *  - all reductions have a fixed order: same inputs -> bitwise same outputs.
+ */
+#ifndef CTN_HIP_H
+#define CTN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTN_OK 0
+#define CTN_ERR_ARG (-1)
+#define CTN_ERR_LAUNCH (-2)
+#define CTN_ERR_WORKSPACE (-3)
+
+int ctn_version(void);
+const char* ctn_last_error(void);
+int ctn_padded_frames(int K);               /* K rounded up to a multiple of 64 */
+
+/* ---- 1x1 convolutions = fp32-MFMA GEMMs ------------------------------------------------
+ * replaces nn.Conv1d(*, *, 1, bias=False): src/conv_tasnet.py:174 (bottleneck), :191 (mask),
+ * :223 and :262 (TemporalBlock), and the Linear of the decoder (:128,:143); autograd's
+ * convolution_backward for the same layers. */
+
+/* Out[m] = op(W) . f(X[m])  (+ residual[m]),   X:[M,Cn,Kp]  Out:[M,R,Kp]
+ *   trans_w = 0: W is [R,Cn] (forward);  trans_w = 1: W is [Cn,R] (input gradient).
+ *   pro_part != NULL (trans_w = 0 only): f(x)[i,k] = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i]
+ *     for k < K, 0 otherwise; (mean_m, rstd_m) are finalised from the [M, pro_nparts, 2] fp64
+ *     (sum, sum of squares) partials of prelu(x) -- global LayerNorm, src/conv_tasnet.py:358-360 --
+ *     and written to pro_ms_out [M,2] when that is non-NULL.
+ *   residual != NULL: TemporalBlock's "out + residual" (src/conv_tasnet.py:243).
+ *   epi_part != NULL: also emits the partials of prelu(Out, epi_alpha) for the NEXT gLN,
+ *     layout [M, ctn_pw_stats_parts(R,Kp), 2] fp64.
+ *   relu_out != 0: Out = relu(.)  (encoder, src/conv_tasnet.py:120). */
+int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn, int K, int Kp, int trans_w,
+                const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+                const float* pro_alpha, float* pro_ms_out,
+                const float* residual, const float* epi_alpha, double* epi_part, int relu_out, void* stream);
+int ctn_pw_stats_parts(int R, int Kp);
+
+/* dN[m] = W^T . dOut[m]   (W:[Cn,R] as stored by the forward layer, dOut:[M,Cn,Kp], dN:[M,R,Kp])
+ * and, fused, the two sums gLN backward needs per utterance, as partials
+ * sums_part [M, ctn_pw_stats_parts(R,Kp), 2] fp64:  S1 = sum gamma*dN,  S2 = sum gamma*dN*xhat,
+ * xhat = (prelu(y,alpha)-ms[m][0])*ms[m][1],  y:[M,R,Kp] the pre-activation input of that norm. */
+int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                     const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                     void* stream);
+
+/* dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]);  f as above when pro_ms ([M,2]) != NULL.
+ * workspace: ctn_pw_wgrad_workspace() bytes of split-K slabs, summed in a fixed order. */
+int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                 const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                 void* workspace, size_t workspace_bytes, void* stream);
+size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
+
+/* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
+ * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
+ * PReLU (:224,:259) and GlobalLayerNorm (:225,:260,:338-361) on either side fused in. */
+
+/* Z[m,h,k] = sum_j D[h,j] * n[m,h,k + j*dilation - pad_left],  zeros outside [0,K);
+ *   pad_left = (P-1)*dilation/2 (non-causal "same") or (P-1)*dilation (causal, = pad + Chomp1d).
+ *   pro_part != NULL: n = gLN(prelu(Y)) as in ctn_pw_gemm; else n = Y.
+ *   epi_part != NULL: partials of prelu(Z, epi_alpha), layout [M, H, 2] fp64. */
+int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
+               const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+               const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, void* stream);
+
+/* Backward of the above.  fused = 1 walks  gLN2 <- PReLU2 <- depthwise <- (gLN1 output)  in one pass:
+ *   in : dN2 (grad of gLN2's output), Dz (= Z of the forward), Y1 (= Y of the forward),
+ *        (g1,b1,a1,ms1) / (g2,a2,ms2) of the two norms, sums2_part from ctn_pw_dgrad_gln
+ *   out: dN1 (grad of gLN1's output), sums1_part [M,H,2] fp64 (S1,S2 for gLN1's backward) and
+ *        pc [F, M, H] per-(utterance, channel) partials, F = ctn_dw_bwd_rows(P, fused):
+ *        rows 0..P-1 dD taps; fused adds P: dgamma2, P+1: dbeta2, P+2: dgamma1, P+3: dbeta1, P+4: dalpha2.
+ * fused = 0: dN2 = dZ, Y1 = the forward input; outputs dN1 = dY and pc rows 0..P-1. */
+int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, const float* D,
+               int M, int H, int K, int Kp, int P, int dilation, int causal, int fused,
+               const float* g1, const float* b1, const float* a1, const float* ms1,
+               const float* g2, const float* a2, const float* ms2,
+               const double* sums2_part, int sums2_nparts, float* pc, double* sums1_part, void* stream);
+int ctn_dw_bwd_rows(int P, int fused);
+
+/* dY = rstd*(gamma*dN - S1/n - xhat*S2/n) * prelu'(Y);  dalpha_part [M*H] = per-row sum over Y<0 of (..)*Y.
+ * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN. */
+int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
+                      const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
+                      float* dalpha_part, void* stream);
+
+/* ---- channel-wise LayerNorm, src/conv_tasnet.py:313-335 (per frame, biased variance) -----
+ * Out = gamma*((a-mean_k)*rstd_k)+beta with a = prelu(Y,alpha) if alpha != NULL else Y.
+ * mean, rstd: [M,Kp] saved for backward. */
+int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int Ch, int K, int Kp,
+                const float* gamma, const float* beta, const float* alpha, void* stream);
+/* dY = [cLN/PReLU backward of dOut  (+ add)] masked by (relu_ref > 0) when relu_ref != NULL.
+ * pc [2, M, Ch]: per-(m,c) partials of dgamma, dbeta;  dalpha_part [ctn_cln_bwd_blocks(M,Kp)]. */
+int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
+                int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
+                const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream);
+int ctn_cln_bwd_blocks(int M, int Kp);
+
+/* out[f][i] = sum_r in[f][r][i]  -- fixed-order finish of the per-(m,c) partials above */
+int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void* stream);
+
+/* ---- encoder / decoder glue -----------------------------------------------------------
+ * encoder  src/conv_tasnet.py:106-121 : ctn_im2col + ctn_pw_gemm(relu_out=1)
+ * decoder  src/conv_tasnet.py:140-145 : ctn_mask_apply + ctn_pw_gemm + ctn_ola (src/utils.py:9-47)
+ * mask non-linearity src/conv_tasnet.py:208-214 (relu | softmax over speakers). */
+int ctn_im2col(const float* mix, float* xcol, int M, int T, int L, int Lp, int K, int Kp, void* stream);
+int ctn_mask_apply(const float* score, const float* w, float* sw, int M, int C, int N, int Kp, int softmax, void* stream);
+int ctn_mask_apply_bwd(const float* dsw, const float* score, const float* w, float* dscore, float* dw,
+                       int M, int C, int N, int Kp, int softmax, void* stream);
+/* est[b, t] = sum_{k*S+l = t} frames[b, l, k]; zeros for t >= (K-1)S+L (the F.pad of :59). frames:[Bn,Lp,Kp] */
+int ctn_ola(const float* frames, float* est, int Bn, int T, int L, int Lp, int K, int Kp, void* stream);
+int ctn_unfold(const float* dest, float* dframes, int Bn, int T, int L, int Lp, int K, int Kp, void* stream);
+
+/* ---- PIT SI-SNR loss, src/pit_criterion.py:12-77 -----------------------------------------
+ * source, estimate: [B,C,T]; lengths: [B] int64; perms: [nperm,C] int32 in itertools order.
+ * estimate is masked IN PLACE for t >= len (reference :38).  Outputs: max_snr [B], best_idx [B] int64,
+ * loss [1] = -mean(max_snr), snr_out [B,C,C] (optional), and the backward tables coef [B,C,4], jsel [B,C]. */
+int ctn_sisnr_pit_fwd(const float* source, float* estimate, const long long* lengths, const int* perms, int nperm,
+                      int B, int C, int T, float* max_snr, long long* best_idx, float* loss, float* snr_out,
+                      float* coef, int* jsel, void* workspace, size_t workspace_bytes, void* stream);
+size_t ctn_sisnr_workspace(int B, int C, int T);
+int ctn_sisnr_chunks(int T);
+/* d_estimate = dloss/d estimate for upstream grads g_loss [1] and/or g_max [B] (either may be NULL) */
+int ctn_sisnr_pit_bwd(const float* source, const float* estimate, const long long* lengths, const float* coef,
+                      const int* jsel, const float* g_loss, const float* g_max, int B, int C, int T, float* d_estimate,
+                      void* stream);
+
+/* ---- optimiser tail, src/solver.py:194-196 (clip_grad_norm_ + Adam.step) on flat buffers ---
+ * g' = grad_scale*g; total = ||g'||2 -> total_norm_out; g' *= min(1, max_norm/(total+1e-6)) if max_norm > 0;
+ * torch.optim.Adam update (no weight decay / amsgrad) with bias corrections for `step` (1-based).
+ * workspace: ctn_optim_parts() doubles. */
+int ctn_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                       float grad_scale, float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                       float* total_norm_out, double* workspace, void* stream);
+int ctn_optim_parts(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTN_HIP_H */

@@ -1,0 +1,355 @@
+"""GPU parity: every HIP stage, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -q
+Tolerances: the north star allows 1e-3 dB on SI-SNR; tensors are compared at <= 2e-5 of their max
+magnitude (fp32 accumulation-order noise through up to 16 blocks), gradients at <= 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ctn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+import conv_tasnet_amd as ctn  # noqa: E402
+from conv_tasnet_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def pad(t, Kp):
+    out = t.new_zeros(t.shape[:-1] + (Kp,))
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ----------------------------------------------------------------------------- library
+def test_library_loaded_is_the_hip_one():
+    assert ctn.lib.ctn_version() >= 100
+    assert torch.cuda.is_available()
+    import os
+    assert os.path.exists(ctn.LIB_PATH)
+
+
+# ----------------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("M,R,Cn,K", [(1, 128, 16, 64), (2, 32, 64, 799), (3, 132, 20, 130), (2, 256, 512, 515),
+                                      (1, 20, 256, 257), (2, 512, 256, 1000)])
+@pytest.mark.parametrize("trans", [False, True])
+def test_pw_gemm_plain(M, R, Cn, K, trans):
+    Kp = ops.padded_frames(K)
+    W = torch.randn((Cn, R) if trans else (R, Cn), generator=g(1))
+    X = pad(torch.randn(M, Cn, K, generator=g(2)), Kp)
+    ref = torch.einsum("oi,mik->mok", (W.t() if trans else W).double(), X.double())
+    out, _ = ops.pw_gemm(W.to(DEV), X.to(DEV), R, Cn, K, trans_w=trans)
+    assert rel_err(out, ref) < 3e-6
+    assert float(out[..., K:].abs().max()) == 0.0 if Kp > K else True
+    res = pad(torch.randn(M, R, K, generator=g(3)), Kp)
+    out2, _ = ops.pw_gemm(W.to(DEV), X.to(DEV), R, Cn, K, trans_w=trans, residual=res.to(DEV))
+    assert rel_err(out2, ref + res.double()) < 3e-6
+
+
+def test_pw_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C-write (guide 3)."""
+    R = Cn = 64
+    K = 128
+    X = torch.arange(Cn * K, dtype=torch.float32).view(1, Cn, K) * 1e-3
+    out, _ = ops.pw_gemm(torch.eye(R).to(DEV), X.to(DEV), R, Cn, K)
+    assert torch.equal(out.cpu(), X)
+
+
+def test_pw_gemm_relu_and_stats_and_prologue():
+    M, B, H, K = 2, 32, 64, 799
+    Kp = ops.padded_frames(K)
+    x = pad(torch.randn(M, B, K, generator=g(4)), Kp)
+    w1 = torch.randn(H, B, generator=g(5)) * 0.2
+    a1 = torch.tensor([0.25])
+    out, _ = ops.pw_gemm(w1.to(DEV), x.to(DEV), H, B, K, relu_out=True)
+    ref = torch.einsum("oi,mik->mok", w1.double(), x.double())
+    assert rel_err(out, ref.clamp_min(0)) < 3e-6
+    h1, st = ops.pw_gemm(w1.to(DEV), x.to(DEV), H, B, K, epi_alpha=a1.to(DEV))
+    p = O.prelu(ref[..., :K], a1.double())
+    s = st.sum(1).cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), p.sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (p ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+    # prologue: out = W2 . gLN(prelu(h1)) + x
+    g1 = torch.randn(1, H, 1, generator=g(6))
+    b1 = torch.randn(1, H, 1, generator=g(7))
+    w2 = torch.randn(B, H, generator=g(8)) * 0.2
+    ms = torch.empty(M, 2, device=DEV)
+    out2, _ = ops.pw_gemm(w2.to(DEV), h1, B, H, K, pro=(st, g1.to(DEV), b1.to(DEV), a1.to(DEV)), residual=x.to(DEV), ms_out=ms)
+    n = O.gln(p, g1.double(), b1.double())
+    ref2 = torch.einsum("oi,mik->mok", w2.double(), n) + x[..., :K].double()
+    assert rel_err(out2[..., :K], ref2) < 5e-6
+    assert float(out2[..., K:].abs().max()) == 0.0
+    mu = p.mean((1, 2))
+    np.testing.assert_allclose(ms[:, 0].cpu().numpy(), mu.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,R,Cn,K", [(2, 64, 32, 799), (1, 20, 256, 300), (3, 512, 256, 1300), (2, 256, 20, 257)])
+def test_pw_wgrad(M, R, Cn, K):
+    Kp = ops.padded_frames(K)
+    dO = pad(torch.randn(M, R, K, generator=g(1)), Kp)
+    X = pad(torch.randn(M, Cn, K, generator=g(2)), Kp)
+    ref = torch.einsum("mrk,mck->rc", dO.double(), X.double())
+    out = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K)
+    assert rel_err(out, ref) < 5e-6
+    out2 = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K)
+    assert torch.equal(out, out2)   # fixed-order reduction: bitwise reproducible
+
+
+# ----------------------------------------------------------------------------- depthwise
+@pytest.mark.parametrize("dil", [1, 2, 8, 128])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("K", [257, 3999])
+def test_dw_plain_fwd_bwd(dil, causal, K):
+    M, H, P = 2, 12, 3
+    Kp = ops.padded_frames(K)
+    y = torch.randn(M, H, K, generator=g(1), dtype=torch.float64).requires_grad_(True)
+    D = torch.randn(H, 1, P, generator=g(2), dtype=torch.float64).requires_grad_(True)
+    z = O.depthwise(y, D, dil, causal)
+    dz = torch.randn(M, H, K, generator=g(3), dtype=torch.float64)
+    z.backward(dz)
+    yd = pad(y.detach().float(), Kp).to(DEV)
+    Dd = D.detach().float().to(DEV)
+    zz, _ = ops.dw_fwd(yd, Dd, K, dil, causal)
+    assert rel_err(zz[..., :K], z) < 3e-6
+    assert float(zz[..., K:].abs().max()) == 0.0
+    pc = torch.empty((P, M, H), device=DEV)
+    dn1 = torch.empty((M, H, Kp), device=DEV)
+    dzd = pad(dz.float(), Kp).to(DEV)
+    ctn.lib.call("ctn_dw_bwd", dzd.data_ptr(), 0, yd.data_ptr(), dn1.data_ptr(), Dd.data_ptr(), M, H, K, Kp, P, dil,
+                 int(causal), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, pc.data_ptr(), 0, 0)
+    assert rel_err(dn1[..., :K], y.grad) < 3e-6
+    dD = ops.reduce_mid(pc, P, M, H).t()
+    assert rel_err(dD, D.grad[:, 0, :]) < 2e-5
+
+
+# ----------------------------------------------------------------------------- blocks
+def _block_case(norm_type, causal, dil_x, K, M=2, B=16, H=32, P=3, seed=0):
+    cfg = O.Config(N=16, L=20, B=B, H=H, P=P, X=dil_x + 1, R=1, C=2, norm_type=norm_type, causal=causal)
+    sd = O.init_params(cfg, seed=seed, dtype=torch.float64)
+    keys = O.block_keys(cfg, 0, dil_x)
+    # make PReLU slopes distinct and gamma/beta non-trivial
+    sd[keys["a1"]] = torch.tensor([0.2], dtype=torch.float64)
+    sd[keys["a2"]] = torch.tensor([0.3], dtype=torch.float64)
+    x = torch.randn(M, B, K, generator=g(seed + 1), dtype=torch.float64)
+    return cfg, sd, keys, x
+
+
+@pytest.mark.parametrize("norm_type,causal", [("gLN", False), ("cLN", True), ("gLN", True), ("cLN", False)])
+@pytest.mark.parametrize("dil_x,K", [(0, 130), (3, 799), (7, 1203), (2, 3700)])
+def test_temporal_block_fwd_bwd(norm_type, causal, dil_x, K):
+    cfg, sd, keys, x = _block_case(norm_type, causal, dil_x, K)
+    leaves = {k: sd[v].clone().requires_grad_(True) for k, v in keys.items()}
+    xr = x.clone().requires_grad_(True)
+    full = dict(sd)
+    for k, v in keys.items():
+        full[v] = leaves[k]
+    ref = O.temporal_block(cfg, xr, full, 0, dil_x)
+    dout = torch.randn(ref.shape, generator=g(9), dtype=torch.float64)
+    ref.backward(dout)
+
+    blk = ctn.conv_tasnet.TemporalBlock(cfg.B, cfg.H, cfg.P, 1, 0, 2 ** dil_x, norm_type, causal).to(DEV)
+    ds = blk.net[3]
+    with torch.no_grad():
+        blk.net[0].weight.copy_(sd[keys["w1"]].float())
+        blk.net[1].weight.copy_(sd[keys["a1"]].float())
+        blk.net[2].gamma.copy_(sd[keys["g1"]].float())
+        blk.net[2].beta.copy_(sd[keys["b1"]].float())
+        ds.net[0].weight.copy_(sd[keys["dw"]].float())
+        ds.prelu().weight.copy_(sd[keys["a2"]].float())
+        ds.norm().gamma.copy_(sd[keys["g2"]].float())
+        ds.norm().beta.copy_(sd[keys["b2"]].float())
+        ds.pointwise().weight.copy_(sd[keys["w2"]].float())
+    xg = x.float().to(DEV).requires_grad_(True)
+    out = blk(xg)
+    assert rel_err(out, ref) < 1e-5
+    out.backward(dout.float().to(DEV))
+    assert rel_err(xg.grad, xr.grad) < 5e-5
+    got = {"w1": blk.net[0].weight, "a1": blk.net[1].weight, "g1": blk.net[2].gamma, "b1": blk.net[2].beta,
+           "dw": ds.net[0].weight, "a2": ds.prelu().weight, "g2": ds.norm().gamma, "b2": ds.norm().beta,
+           "w2": ds.pointwise().weight}
+    for k, p in got.items():
+        assert rel_err(p.grad, leaves[k].grad) < 1e-4, k
+
+
+# ----------------------------------------------------------------------------- whole model vs the reference's own outputs
+def _load_model(gd):
+    N, L, B, H, P, X, R, C = [int(v) for v in gd["cfg"]]
+    m = ctn.ConvTasNet(N, L, B, H, P, X, R, C, norm_type=str(gd["norm_type"]), causal=bool(int(gd["causal"])),
+                       mask_nonlinear=str(gd["mask_nonlinear"]))
+    m.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in gd.items() if k.startswith("p:")})
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["model_tiny_gln", "model_tiny_cln_causal", "model_c3_softmax", "model_c3_relu_x4"])
+def test_model_matches_reference_golden(name):
+    gd = load_golden(name)
+    m = _load_model(gd)
+    mix = torch.from_numpy(gd["mixture"]).to(DEV)
+    src = torch.from_numpy(gd["source"]).to(DEV)
+    lens = torch.from_numpy(gd["lengths"]).to(DEV)
+    est = m(mix)
+    ref = torch.from_numpy(gd["est_source_raw"])
+    assert est.shape == ref.shape
+    assert rel_err(est, ref) < 2e-5
+    loss, max_snr, est_m, reord = ctn.cal_loss(src, est, lens)
+    # north-star budget: 1e-3 dB
+    assert abs(float(loss) - float(gd["loss"])) < 1e-3
+    assert np.abs(max_snr.detach().cpu().numpy() - gd["max_snr"]).max() < 1e-3
+    assert est_m.data_ptr() == est.data_ptr()            # masked in place, like the reference
+    assert rel_err(est_m, torch.from_numpy(gd["est_source_masked"])) < 2e-5
+    assert rel_err(reord, torch.from_numpy(gd["reorder"])) < 2e-5
+    loss.backward()
+    for k, p in m.named_parameters():
+        refg = torch.from_numpy(gd["g:" + k])
+        assert p.grad is not None, k
+        assert rel_err(p.grad, refg) < 2e-3, (k, rel_err(p.grad, refg))
+
+
+def test_model_intermediates_tiny():
+    gd = load_golden("model_tiny_gln")
+    m = _load_model(gd)
+    mix = torch.from_numpy(gd["mixture"]).to(DEV)
+    with torch.no_grad():
+        w = m.encoder(mix)
+        assert rel_err(w, torch.from_numpy(gd["i_encoder"])) < 1e-5
+        mask = m.separator(w)
+        assert rel_err(mask, torch.from_numpy(gd["i_mask"])) < 1e-4
+        est = m.decoder(w, mask)
+        K = w.shape[-1]
+        Tc = (K - 1) * 10 + 20
+        assert rel_err(est, torch.from_numpy(gd["est_source_raw"])[..., :Tc]) < 1e-4
+        blk = m.separator.network[2][0][0]
+        out = blk(torch.from_numpy(gd["i_bottleneck"]).to(DEV))
+        assert rel_err(out, torch.from_numpy(gd["i_block00"])) < 1e-5
+
+
+# ----------------------------------------------------------------------------- loss
+def test_pit_known_answer_reference_main():
+    gd = load_golden("pit_main_int")
+    src = torch.from_numpy(gd["source"]).float().to(DEV)
+    est = torch.from_numpy(gd["estimate"]).float().to(DEV)
+    loss, max_snr, _, _ = ctn.cal_loss(src, est, torch.from_numpy(gd["lengths"]).to(DEV))
+    assert abs(float(loss) - 45.9221) < 1e-3
+    assert np.abs(max_snr.cpu().numpy() - gd["max_snr"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_pit_float_ragged(C):
+    gd = load_golden("pit_float_c%d" % C)
+    src = torch.from_numpy(gd["source"]).to(DEV)
+    est0 = torch.from_numpy(gd["estimate"]).to(DEV).requires_grad_(True)
+    lens = torch.from_numpy(gd["lengths"]).to(DEV)
+    est = est0 * 1.0
+    loss, max_snr, est_m, reord = ctn.cal_loss(src, est, lens)
+    assert abs(float(loss) - float(gd["loss"])) < 1e-3
+    assert np.abs(max_snr.detach().cpu().numpy() - gd["max_snr"]).max() < 1e-3
+    max2, perms, idx = ctn.cal_si_snr_with_pit(src, est_m.detach().clone(), lens)
+    assert np.array_equal(perms.cpu().numpy(), gd["perms"])
+    assert np.array_equal(idx.cpu().numpy(), gd["idx"])
+    np.testing.assert_allclose(est_m.detach().cpu().numpy(), gd["est_masked"], atol=1e-6)
+    np.testing.assert_allclose(reord.detach().cpu().numpy(), gd["reorder"], atol=1e-6)
+    loss.backward()
+    assert rel_err(est0.grad, torch.from_numpy(gd["grad_estimate"])) < 2e-3
+
+
+def test_pit_empty_tail_and_full_length_agree():
+    """Zero-padded tail with shorter length == truncated signal."""
+    B, C, T = 2, 2, 5000
+    src = torch.randn(B, C, T, generator=g(1))
+    est = src + 0.1 * torch.randn(B, C, T, generator=g(2))
+    n = 4321
+    l1, m1, _, _ = ctn.cal_loss(src.to(DEV), est.clone().to(DEV), torch.tensor([n, n]).to(DEV))
+    l2, m2, _, _ = ctn.cal_loss(src[..., :n].contiguous().to(DEV), est[..., :n].contiguous().to(DEV),
+                                torch.tensor([n, n]).to(DEV))
+    assert abs(float(l1) - float(l2)) < 1e-4
+
+
+# ----------------------------------------------------------------------------- overlap-add
+@pytest.mark.parametrize("name", ["ola_f_37_20_10", "ola_f_50_16_8"])
+def test_overlap_and_add_golden(name):
+    gd = load_golden(name)
+    out = ctn.overlap_and_add(torch.from_numpy(gd["signal"]).to(DEV), int(gd["step"]))
+    np.testing.assert_allclose(out.cpu().numpy(), gd["result"], atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- optimiser tail
+def test_clip_adam_matches_torch():
+    n = 100003
+    p0 = torch.randn(n, generator=g(1))
+    ptorch = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ptorch], lr=1e-3)
+    p = p0.clone().to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    ws = torch.empty(ctn.lib.ctn_optim_parts(), dtype=torch.float64, device=DEV)
+    tn = torch.empty(1, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g(10 + step)) * (3.0 if step == 2 else 0.01)
+        ptorch.grad = grad.clone()
+        total = torch.nn.utils.clip_grad_norm_([ptorch], 5.0)
+        opt.step()
+        gd = grad.to(DEV)
+        ctn.lib.call("ctn_clip_adam_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1.0, 5.0, 1e-3,
+                     0.9, 0.999, 1e-8, step, tn.data_ptr(), ws.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert abs(float(tn) - float(total)) < 1e-4 * float(total)
+        assert rel_err(p, ptorch.data) < 1e-6
+
+
+# ----------------------------------------------------------------------------- full-size properties (paper config)
+def _paper(M=1, T=32000, seed=0):
+    cfg = O.Config(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2)
+    torch.manual_seed(seed)
+    m = ctn.ConvTasNet(cfg.N, cfg.L, cfg.B, cfg.H, cfg.P, cfg.X, cfg.R, cfg.C).to(DEV)
+    mix, lens, src = O.synth_batch(0, M, T)
+    return cfg, m, mix, lens, src
+
+
+def test_paper_config_parity_vs_oracle_one_utterance():
+    """BASELINE configs[1] at M=1: waveforms, SI-SNR (<= 1e-3 dB) and all 294 gradients vs the CPU oracle."""
+    cfg, m, mix, lens, src = _paper(M=1)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    est_ref = O.forward(cfg, sd, mix)
+    loss_ref, max_ref, _, _ = O.cal_loss(src, est_ref, lens)
+    loss_ref.backward()
+    est = m(mix.to(DEV))
+    assert rel_err(est, est_ref) < 1e-4
+    loss, max_snr, _, _ = ctn.cal_loss(src.to(DEV), est, lens.to(DEV))
+    assert abs(float(loss) - float(loss_ref)) < 1e-3
+    loss.backward()
+    worst = 0.0
+    for k, p in m.named_parameters():
+        e = rel_err(p.grad, sd[k].grad)
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print("paper config: |dloss| = %.2e dB, worst grad rel err %.2e" % (abs(float(loss) - float(loss_ref)), worst))
+
+
+def test_paper_config_batch_properties():
+    """Size-independent properties at M=4: per-utterance independence, bitwise determinism, zero tail."""
+    cfg, m, mix, lens, src = _paper(M=4, T=32005)
+    with torch.no_grad():
+        e1 = m(mix.to(DEV))
+        e2 = m(mix.to(DEV))
+        assert torch.equal(e1, e2)
+        e_single = m(mix[2:3].to(DEV))
+        assert rel_err(e1[2:3], e_single) < 1e-6          # utterances do not interact (gLN is per utterance)
+        assert float(e1[..., 32000:].abs().max()) == 0.0   # T - T_conv tail is exact zeros
+        # scaling the mixture scales nothing through gLN'd masks but the encoder: est(a*x) = a*est(x) for a > 0
+        e3 = m((2.0 * mix).to(DEV))
+        assert rel_err(e3, 2.0 * e1) < 1e-3
