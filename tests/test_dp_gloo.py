@@ -1,0 +1,73 @@
+"""N>1 path on CPU: two gloo ranks, sharded minibatch, one gradient all-reduce == the full-batch gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ctn_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import conv_tasnet_amd  # noqa: F401
+    from conv_tasnet_amd import parallel
+    w, r, dev = parallel.init_distributed(backend="gloo")
+    assert (w, r) == (world, rank) and dev.type == "cpu"
+    cfg = O.Config(N=16, L=20, B=8, H=16, P=3, X=2, R=1, C=2)
+    sd = O.init_params(cfg, seed=5 + rank)            # deliberately different per rank ...
+    params = [torch.nn.Parameter(v) for v in sd.values()]
+    holder = torch.nn.ParameterList(params)
+    parallel.broadcast_parameters(holder, src=0)      # ... until rank 0's weights are broadcast
+    mix, lens, src = O.synth_batch(40, 4, 2000)        # the same global batch on every rank
+    smix, slens, ssrc = parallel.shard_batch((mix, lens, src))
+    assert smix.shape[0] == 2
+    leaves = dict(zip(sd.keys(), params))
+    loss, _, _, _ = O.cal_loss(ssrc, O.forward(cfg, leaves, smix), slens)
+    loss.backward()
+    scale = parallel.allreduce_gradients(params)
+    assert scale == 1.0
+    torch.save({"grads": [p.grad.clone() for p in params], "w0": params[0].detach().clone(), "loss": float(loss)},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["w0"], r1["w0"])                       # broadcast happened
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)                                 # every rank holds the same reduced gradient
+    # single-process reference: full batch of 4, loss = -mean over the batch
+    cfg = O.Config(N=16, L=20, B=8, H=16, P=3, X=2, R=1, C=2)
+    sd = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=5).items()}
+    mix, lens, src = O.synth_batch(40, 4, 2000)
+    loss, _, _, _ = O.cal_loss(src, O.forward(cfg, sd, mix), lens)
+    loss.backward()
+    for g, p in zip(r0["grads"], sd.values()):
+        assert float((g - p.grad).abs().max()) <= 1e-5 * float(p.grad.abs().max()) + 1e-8
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - float(loss)) < 1e-5
+
+
+def test_shard_batch_rejects_ragged_split():
+    from conv_tasnet_amd import parallel
+    with pytest.raises(ValueError):
+        parallel.shard_batch((torch.zeros(5, 3),), rank=0, world=2)
+    a, = parallel.shard_batch((torch.arange(8).view(8, 1),), rank=1, world=4)
+    assert a.flatten().tolist() == [2, 3]

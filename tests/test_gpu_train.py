@@ -1,0 +1,141 @@
+"""GPU: the callers around the hot path -- Solver trajectory vs the reference Solver, FlatAdam, checkpoints,
+separate(), evaluate()."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ctn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+import conv_tasnet_amd as ctn  # noqa: E402
+from conv_tasnet_amd.optim import FlatAdam  # noqa: E402
+from conv_tasnet_amd.solver import Solver  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _traj_setup():
+    g = load_golden("solver_traj")
+    N, L, B, H, P, X, R, C = [int(v) for v in g["cfg"]]
+    m = ctn.ConvTasNet(N, L, B, H, P, X, R, C)
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p0:")})
+    T = int(g["T"])
+    batches = [O.synth_batch(900 + 2 * i, 2, T) for i in range(3)]
+    return g, m.to(DEV), batches
+
+
+@pytest.mark.parametrize("flat", [True, False])
+def test_solver_trajectory_matches_reference_solver(tmp_path, flat):
+    """Same weights, batches, Adam(1e-3), clip 5, 4 epochs as the run recorded from src/solver.py."""
+    g, m, batches = _traj_setup()
+    opt = FlatAdam(m.parameters(), lr=1e-3) if flat else torch.optim.Adam(m.parameters(), lr=1e-3)
+    arg = (1, int(g["epochs"]), 1, 0, 5, str(tmp_path), 0, "", "final.pth.tar", 1000, 0, 0, "x")
+    s = Solver({"tr_loader": batches, "cv_loader": batches[:1]}, m, opt, arg)
+    s.train()
+    np.testing.assert_allclose(np.array(s.iter_losses), g["iter_losses"], atol=2e-3)
+    np.testing.assert_allclose(s.tr_loss.numpy(), g["tr_loss"], atol=2e-3)       # includes the (n+1) divisor
+    np.testing.assert_allclose(s.cv_loss.numpy(), g["cv_loss"], atol=2e-3)
+    assert abs(opt.param_groups[0]["lr"] - float(g["final_lr"])) < 1e-12
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["p1:" + k], atol=3e-4, err_msg=k)
+    pkg = torch.load(tmp_path / "final.pth.tar", weights_only=False)
+    assert sorted(pkg.keys()) == sorted(str(k) for k in g["pkg_keys"]) and pkg["epoch"] == int(g["pkg_epoch"])
+
+
+def test_flatadam_state_interchanges_with_torch_adam():
+    g, m, batches = _traj_setup()
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    for mix, lens, src in batches[:2]:
+        opt.zero_grad()
+        loss = ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0]
+        loss.backward()
+        opt.step(max_grad_norm=5.0)
+    sd = opt.state_dict()
+    # a torch Adam over a copy of the model picks the state up and continues identically
+    m2 = ctn.ConvTasNet(m.N, m.L, m.B, m.H, m.P, m.X, m.R, m.C).to(DEV)
+    m2.load_state_dict(m.state_dict())
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    opt2.load_state_dict(sd)
+    mix, lens, src = batches[2]
+    for mm, oo in ((m, opt), (m2, opt2)):
+        oo.zero_grad()
+        ctn.cal_loss(src.to(DEV), mm(mix.to(DEV)), lens.to(DEV))[0].backward()
+        if oo is opt:
+            oo.step(max_grad_norm=5.0)
+        else:
+            torch.nn.utils.clip_grad_norm_(mm.parameters(), 5.0)
+            oo.step()
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert float((a - b).abs().max()) < 2e-6, k
+    # and the other way round
+    opt3 = FlatAdam(m2.parameters(), lr=1e-3)
+    opt3.load_state_dict(opt2.state_dict())
+    assert opt3._step == 3
+    # grads live in one flat buffer (the all-reduce payload)
+    p = next(m.parameters())
+    assert p.grad.data_ptr() == opt.flat_grads.data_ptr()
+
+
+def test_checkpoint_resume(tmp_path):
+    g, m, batches = _traj_setup()
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    arg = (1, 2, 1, 0, 5, str(tmp_path), 1, "", "best.pth.tar", 1000, 0, 0, "x")
+    Solver({"tr_loader": batches, "cv_loader": batches[:1]}, m, opt, arg).train()
+    ck = tmp_path / "checkpoint_models" / "epoch2.pth.tar"
+    assert ck.exists()
+    m2 = ctn.ConvTasNet.load_model(str(ck)).to(DEV)
+    opt2 = FlatAdam(m2.parameters(), lr=1e-3)
+    arg2 = (1, 1, 1, 0, 5, str(tmp_path), 0, str(ck), "best2.pth.tar", 1000, 0, 0, "x")
+    s2 = Solver({"tr_loader": batches, "cv_loader": batches[:1]}, m2, opt2, arg2)
+    assert s2.start_epoch == 2 and s2.epochs == 1 + 2 + 1          # reference rule: epochs + start_epoch + 1
+    assert opt2._step == 6
+    s2.train()
+    assert len(s2.iter_losses) == 2 * 4
+
+
+def test_separate_writes_reference_named_files(tmp_path):
+    from scipy.io import wavfile
+    from conv_tasnet_amd.separate import separate
+    torch.manual_seed(0)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2)
+    path = str(tmp_path / "m.pth.tar")
+    torch.save(ctn.ConvTasNet.serialize(m, torch.optim.Adam(m.parameters()), 1), path)
+    mixdir = tmp_path / "mix"
+    mixdir.mkdir()
+    mix, _, _ = O.synth_batch(0, 2, 4000)
+    wavfile.write(str(mixdir / "utt_a.wav"), 8000, mix[0].numpy())
+    wavfile.write(str(mixdir / "utt_b.wav"), 8000, mix[1, :3000].numpy())
+    out = tmp_path / "out"
+    separate(path, str(mixdir), None, str(out), 1, 8000, 2)
+    names = sorted(os.listdir(out))
+    # 'utt_a.wav'.strip('.wav') == 'utt_' : the reference strips characters, not the suffix
+    assert names == sorted(["utt_.wav", "utt__s1.wav", "utt__s2.wav", "utt_b.wav", "utt_b_s1.wav", "utt_b_s2.wav"])
+    sr, s1 = wavfile.read(str(out / "utt_b_s1.wav"))
+    assert sr == 8000 and len(s1) == 3000
+    with torch.no_grad():
+        ref = m.to(DEV)(mix[1:2, :3000].to(DEV))[0, 0].cpu().numpy()
+    np.testing.assert_allclose(s1, ref, atol=1e-5)
+
+
+def test_evaluate_sisnri_matches_oracle(capsys):
+    from conv_tasnet_amd.evaluate import evaluate, cal_SISNR
+    torch.manual_seed(1)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV)
+    mix, lens, src = O.synth_batch(7, 2, 3000)
+    lens = torch.tensor([3000, 2500])
+    mix[1, 2500:] = 0
+    src[1, :, 2500:] = 0
+    got = evaluate(m, [(mix, lens, src)], use_cuda=True, verbose=False)
+    cfg = O.Config(32, 20, 16, 32, 3, 2, 1, 2)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    est = O.forward(cfg, sd, mix)
+    _, _, _, reord = O.cal_loss(src, est, lens)
+    want = np.mean([O.cal_sisnri_np(src[b, :, :n].double().numpy(), reord[b, :, :n].double().numpy(),
+                                    mix[b, :n].double().numpy()) for b, n in enumerate([3000, 2500])])
+    assert abs(got - want) < 1e-3
+    x = np.random.RandomState(0).randn(1000)
+    assert abs(cal_SISNR(x, x) - O.cal_sisnr_np(x, x)) < 1e-9
