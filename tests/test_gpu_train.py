@@ -117,7 +117,9 @@ def test_separate_writes_reference_named_files(tmp_path):
     sr, s1 = wavfile.read(str(out / "utt_b_s1.wav"))
     assert sr == 8000 and len(s1) == 3000
     with torch.no_grad():
-        ref = m.to(DEV)(mix[1:2, :3000].to(DEV))[0, 0].cpu().numpy()
+        padded = mix.clone()
+        padded[1, 3000:] = 0          # the batch is zero-padded to its longest utterance, as in the reference loader
+        ref = m.to(DEV)(padded.to(DEV))[1, 0, :3000].cpu().numpy()
     np.testing.assert_allclose(s1, ref, atol=1e-5)
 
 
