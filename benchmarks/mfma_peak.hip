@@ -1,0 +1,52 @@
+// Bare fp32-MFMA issue-rate probe: what does v_mfma_f32_32x32x2_f32 sustain on THIS box, on random vs zero operands,
+// at 1, 2 and 4 waves per SIMD?  (MI355X_MICROARCH.md, DVFS give-back: MFMA-dense loops hold 1.5-1.7 GHz.)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ in, float* __restrict__ out, int iters,
+                                             unsigned long long* clk) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = in[threadIdx.x], b = in[threadIdx.x + 256];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        a += 1e-9f;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+int main() {
+    float *in, *out; unsigned long long* clk;
+    hipMalloc(&in, 512 * 4); hipMalloc(&out, 256 * 2048 * 4 * 4); hipMalloc(&clk, 16);
+    float h[512];
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int i = 0; i < 512; ++i) h[i] = mode ? 0.f : (float)rand() / RAND_MAX - 0.5f;
+        hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
+        for (int bpc = 1; bpc <= 4; bpc *= 2) {
+            const int blocks = 256 * bpc, iters = 20000;
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, 0, in, out, iters, clk);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+            double flop = (double)blocks * 4 /*waves*/ * iters * 4 /*acc*/ * 4096.0;
+            printf("%s operands, %d wave(s)/SIMD: %.1f TFLOP/s, %.2f ms, in-kernel clock %.2f GHz\n", mode ? "zero  " : "random",
+                   bpc, flop / ms / 1e9, ms, (double)hc[0] / (double)hc[1] * 0.1);
+        }
+    }
+    return 0;
+}

@@ -14,17 +14,40 @@
 // (64 cycles) consumes one A and one B dword per lane, so LDS bandwidth is
 // never the bound; the fused prologue/epilogue work rides in the VALU shadow.
 #include "ctn_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int LDA = 132, LDB = 132;   // row stride (floats) of the LDS images; 16-B aligned rows
+constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
 
 enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4 };
+
+// Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
+// in 32x32 MFMA tiles.  Smaller tiles trade operand reuse (plentiful: one fp32 MFMA = 64 cycles for one
+// A and one B dword per lane) for finer load balance over the 256 CUs.
+template <int BM_, int BN_, int WGM_, int WGN_, int BK_ = 16>
+struct Tile {
+    static constexpr int TM = BM_, TN = BN_, WGM = WGM_, WGN = WGN_, TK = BK_;
+    static constexpr int WM = BM_ / WGM_, WN = BN_ / WGN_;
+    static constexpr int MT = WM / 32, NTL = WN / 32;
+    static constexpr int LDA = BM_ + 4, LDB = BN_ + 4, LDS_ST = WN + 4;
+    static constexpr int MAIN_FLOATS = 2 * BK_ * (LDA + LDB);
+    static constexpr int STAGE_FLOATS = 4 * 32 * LDS_ST;
+    static constexpr int SMEM_FLOATS = MAIN_FLOATS > STAGE_FLOATS ? MAIN_FLOATS : STAGE_FLOATS;
+    static_assert(WGM_ * WGN_ == 4 && WM % 32 == 0 && WN % 32 == 0, "4 waves of 32x32 MFMA tiles");
+};
+using T128x128 = Tile<128, 128, 2, 2>;
+using T128x64 = Tile<128, 64, 2, 2>;
+using T64x128 = Tile<64, 128, 2, 2>;
+using T64x64 = Tile<64, 64, 2, 2>;
+using T128x64w = Tile<128, 64, 4, 1>;
+using T64x64k32 = Tile<64, 64, 2, 2, 32>;
+using T128x64k32 = Tile<128, 64, 2, 2, 32>;
+using T128x128k32 = Tile<128, 128, 2, 2, 32>;
 
 struct PwArgs {
     const float* W;      // TRANS_W=0: [R, Cn]   TRANS_W=1: [Cn, R]
@@ -45,19 +68,24 @@ struct PwArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int TRANS_W, int PRO, int EPI>
+template <typename TL, int TRANS_W, int PRO, int EPI>
 __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+    constexpr int TM = TL::TM, TN = TL::TN, LDA = TL::LDA, LDB = TL::LDB, MT = TL::MT, NTL = TL::NTL;
+    constexpr int WM = TL::WM, WN = TL::WN, BK = TL::TK;
+    constexpr int A_L = TM * BK / 1024, B_L = TN * BK / 1024;    // float4 loads per thread per k-tile
+    constexpr int AT = BK / 4;                                  // threads per weight row (TRANS_W = 0)
+    __shared__ __attribute__((aligned(16))) float smem[TL::SMEM_FLOATS];
     __shared__ double red[NT / 64];
+    float* const As = smem;                       // [2][BK][LDA]
+    float* const Bs = smem + 2 * BK * LDA;        // [2][BK][LDB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / TL::WGN, wn = wave % TL::WGN;
     int bid = blockIdx.x;
     const int rt = bid % a.tiles_r; bid /= a.tiles_r;
     const int ct = bid % a.tiles_c;
     const int m = bid / a.tiles_c;
-    const int r0 = rt * BM, c0 = ct * BN;
+    const int r0 = rt * TM, c0 = ct * TN;
     const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
     float* __restrict__ Om = a.Out + (size_t)m * a.R * a.Kp;
 
@@ -72,30 +100,29 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
         }
     }
 
-    // ---- global -> register staging maps -----------------------------------
-    // A (weights): TRANS_W=0 reads W[r][c..c+3] (thread: c4 = tid&3, r = tid>>2 (+64));
-    //              TRANS_W=1 reads W[c][r..r+3] (thread: r4 = tid&31, c = tid>>5 (+8)).
-    // B (activations): X[i][k..k+3] (thread: k4 = tid&31, i = tid>>5 (+8)).
-    float4 ra[2], rb[2];
+    // ---- global -> register staging maps (float4 each) ---------------------------------------
+    // A (weights): TRANS_W=0 reads W[r][c..c+3]: c4 = tid&3, r = tid>>2 (+64 j)
+    //              TRANS_W=1 reads W[c][r..r+3]: r4 = tid % (TM/4), c = tid / (TM/4) (+ (1024/TM) j)
+    // B (activations): X[i][k..k+3]:            k4 = tid % (TN/4), i = tid / (TN/4) (+ (1024/TN) j)
     const int nk = (a.Cn + BK - 1) / BK;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, float4 (&ra)[A_L], float4 (&rb)[B_L]) {
         const int kc = kt * BK;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < A_L; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (TRANS_W == 0) {
-                const int r = r0 + (tid >> 2) + 64 * j, c = kc + (tid & 3) * 4;
+                const int r = r0 + tid / AT + (NT / AT) * j, c = kc + (tid % AT) * 4;
                 if (r < a.R && c < a.Cn) v = ld4(a.W + (size_t)r * a.Cn + c);
             } else {
-                const int c = kc + (tid >> 5) + 8 * j, r = r0 + (tid & 31) * 4;
+                const int c = kc + tid / (TM / 4) + (1024 / TM) * j, r = r0 + (tid % (TM / 4)) * 4;
                 if (c < a.Cn && r < a.R) v = ld4(a.W + (size_t)c * a.R + r);
             }
             ra[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = kc + (tid >> 5) + 8 * j, k = c0 + (tid & 31) * 4;
+        for (int j = 0; j < B_L; ++j) {
+            const int i = kc + tid / (TN / 4) + (1024 / TN) * j, k = c0 + (tid % (TN / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < a.Cn && k < a.Kp) {
                 v = ld4(Xm + (size_t)i * a.Kp + k);
@@ -110,60 +137,82 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
             rb[j] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const float4 (&ra)[A_L], const float4 (&rb)[B_L]) {
+        float* const Ab = As + buf * BK * LDA;
+        float* const Bb = Bs + buf * BK * LDB;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < A_L; ++j) {
             if constexpr (TRANS_W == 0) {
-                const int r = (tid >> 2) + 64 * j, c = (tid & 3) * 4;
-                As[buf][c + 0][r] = ra[j].x;
-                As[buf][c + 1][r] = ra[j].y;
-                As[buf][c + 2][r] = ra[j].z;
-                As[buf][c + 3][r] = ra[j].w;
+                const int r = tid / AT + (NT / AT) * j, c = (tid % AT) * 4;
+                Ab[(c + 0) * LDA + r] = ra[j].x;
+                Ab[(c + 1) * LDA + r] = ra[j].y;
+                Ab[(c + 2) * LDA + r] = ra[j].z;
+                Ab[(c + 3) * LDA + r] = ra[j].w;
             } else {
-                const int c = (tid >> 5) + 8 * j, r = (tid & 31) * 4;
-                *reinterpret_cast<float4*>(&As[buf][c][r]) = ra[j];
+                const int c = tid / (TM / 4) + (1024 / TM) * j, r = (tid % (TM / 4)) * 4;
+                *reinterpret_cast<float4*>(Ab + c * LDA + r) = ra[j];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = (tid >> 5) + 8 * j, k = (tid & 31) * 4;
-            *reinterpret_cast<float4*>(&Bs[buf][i][k]) = rb[j];
+        for (int j = 0; j < B_L; ++j) {
+            const int i = tid / (TN / 4) + (1024 / TN) * j, k = (tid % (TN / 4)) * 4;
+            *reinterpret_cast<float4*>(Bb + i * LDB + k) = rb[j];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NTL];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int l31 = lane & 31, lhi = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int buf) {
+        const float* const Ab = As + buf * BK * LDA + wm * WM + l31;
+        const float* const Bb = Bs + buf * BK * LDB + wn * WN + l31;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + lhi;
-            const float a0 = As[buf][kk][wm * 64 + l31];
-            const float a1 = As[buf][kk][wm * 64 + 32 + l31];
-            const float b0 = Bs[buf][kk][wn * 64 + l31];
-            const float b1 = Bs[buf][kk][wn * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[MT], bv[NTL];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = Ab[kk * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) bv[j] = Bb[kk * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    // Software pipeline, prefetch distance 2: while tile kt is multiplied out of LDS, tile kt+1 sits in one register
+    // set (written to the other LDS buffer after the MFMAs) and tile kt+2 is in flight into the second set -- the
+    // global-load latency is covered by two k-tiles of MFMA work instead of one.
+    float4 pa[A_L], pb[B_L], qa[A_L], qb[B_L];
+    load_tile(0, pa, pb);
+    store_tile(0, pa, pb);
+    if (nk > 1) load_tile(1, pa, pb);
+    if (nk > 2) load_tile(2, qa, qb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);
+        if (kt + 1 < nk) store_tile(1, pa, pb);
         __syncthreads();
+        if (kt + 3 < nk) load_tile(kt + 3, pa, pb);
+        if (kt + 1 < nk) {
+            compute(1);
+            if (kt + 2 < nk) store_tile(0, qa, qb);
+            __syncthreads();
+            if (kt + 4 < nk) load_tile(kt + 4, qa, qb);
+        }
     }
 
-    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5) ----
+    // ---- epilogue: each wave transposes its accumulators through a private LDS patch (32 rows at a
+    // time) so that global traffic is 16 bytes per lane along frames instead of 64 dword accesses.
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     float e_alpha = 0.f, b_mean = 0.f, b_rstd = 1.f;
     if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
     if constexpr (EPI == EPI_GLN_BWD) {
@@ -171,41 +220,53 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
         b_mean = a.bwd_ms[2 * m];
         b_rstd = a.bwd_ms[2 * m + 1];
     }
+    constexpr int LST = TL::LDS_ST;
+    constexpr int C4 = WN / 4;              // lanes per staged row
+    constexpr int RPP = 64 / C4;            // rows per pass
+    float* const stage = smem + wave * 32 * LST;
     float s1 = 0.f, s2 = 0.f;
+    const size_t mbase = (size_t)m * a.R * a.Kp;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = r0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-            float g = 0.f;
-            if constexpr (EPI == EPI_GLN_BWD) g = (r < a.R) ? a.bwd_gamma[r] : 0.f;
+        for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int k = c0 + wn * 64 + nt * 32 + l31;
-                float v = acc[mt][nt][e];
-                const bool ok = (r < a.R) && (k < a.Kp);
+            for (int e = 0; e < 16; ++e)
+                stage[((e & 3) + 8 * (e >> 2) + 4 * lhi) * LST + nt * 32 + l31] = acc[mt][nt][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 32 / RPP; ++p) {
+            const int rl = p * RPP + lane / C4, cl = (lane % C4) * 4;
+            const int r = r0 + wm * WM + mt * 32 + rl, k = c0 + wn * WN + cl;
+            float4 v = *reinterpret_cast<const float4*>(stage + rl * LST + cl);
+            if (r < a.R && k < a.Kp) {
                 const size_t off = (size_t)r * a.Kp + k;
                 if constexpr (EPI == EPI_RESIDUAL) {
-                    if (ok) v += a.residual[(size_t)m * a.R * a.Kp + off];
+                    const float4 q = ld4(a.residual + mbase + off);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
-                if constexpr (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                if constexpr (EPI == EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
                 if constexpr (EPI == EPI_PRELU_STATS) {
-                    const float p = prelu_f(v, e_alpha);
-                    s1 += p;
-                    s2 += p * p;
+                    const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
+                    const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
+                    s1 += (p0 + p1) + (p2 + p3);
+                    s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
                 }
                 if constexpr (EPI == EPI_GLN_BWD) {
-                    if (ok) {
-                        const float y = a.bwd_y[(size_t)m * a.R * a.Kp + off];
-                        const float xh = (prelu_f(y, e_alpha) - b_mean) * b_rstd;
-                        const float t = g * v;
-                        s1 += t;
-                        s2 += t * xh;
-                    }
+                    const float4 y = ld4(a.bwd_y + mbase + off);
+                    const float g = a.bwd_gamma[r];
+                    const float t0 = g * v.x, t1 = g * v.y, t2 = g * v.z, t3 = g * v.w;
+                    const float x0 = (prelu_f(y.x, e_alpha) - b_mean) * b_rstd, x1 = (prelu_f(y.y, e_alpha) - b_mean) * b_rstd;
+                    const float x2 = (prelu_f(y.z, e_alpha) - b_mean) * b_rstd, x3 = (prelu_f(y.w, e_alpha) - b_mean) * b_rstd;
+                    s1 += (t0 + t1) + (t2 + t3);
+                    s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
                 }
-                if (ok) Om[off] = v;
+                *reinterpret_cast<float4*>(Om + off) = v;
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
         const double d1 = block_sum<double, NT>((double)s1, red);
@@ -363,9 +424,80 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
 
 }  // namespace
 
+// ---- tile selection ------------------------------------------------------------------------
+// id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32
+static int g_tile_override = -2;   // -2: not read yet, -1: heuristic
+
+static void tile_dims(int id, int* tm, int* tn) {
+    static const int d[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}};
+    *tm = d[id][0];
+    *tn = d[id][1];
+}
+
+static int pick_tile(int M, int R, int Kp) {
+    if (g_tile_override == -2) {
+        const char* e = getenv("CTN_PW_TILE");
+        g_tile_override = (e && *e) ? atoi(e) : -1;
+        if (g_tile_override < -1 || g_tile_override > 7) g_tile_override = -1;
+    }
+    if (g_tile_override >= 0) return g_tile_override;
+    // Measured on MI355X (benchmarks/gemm_sweep.py, paper shapes): 64x64 tiles win every variant -- 3200 / 1600
+    // workgroups balance over the 256 CUs far better than 800 / 400 tiles of 128x128, and one fp32 MFMA (64 cycles)
+    // needs so little operand bandwidth that the smaller tile's lower reuse costs nothing.
+    (void)M; (void)R; (void)Kp;
+    const int best_id = 3;
+    return best_id;
+}
+
+template <typename TL>
+static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd,
+                        hipStream_t st) {
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(NT);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    else if (trans_w) {
+        if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+    } else if (pro) {
+        if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+}
+
+static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const int id = pick_tile(a.M, a.R, a.Kp);
+    int tm, tn;
+    tile_dims(id, &tm, &tn);
+    a.tiles_r = ctn_cdiv(a.R, tm);
+    a.tiles_c = ctn_cdiv(a.Kp, tn);
+    switch (id) {
+        case 1: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 2: launch_tile<T64x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 3: launch_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 4: launch_tile<T128x64w>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 5: launch_tile<T64x64k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 6: launch_tile<T128x64k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 7: launch_tile<T128x128k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        default: launch_tile<T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+    }
+}
+
 extern "C" {
 
-int ctn_pw_stats_parts(int R, int Kp) { return ctn_cdiv(R, BM) * ctn_cdiv(Kp, BN); }
+// experiment / autotune hook: force a tile id (0..4) for every ctn_pw_gemm / ctn_pw_dgrad_gln, -1 = heuristic
+int ctn_tune_pw_tile(int id) {
+    if (id < -1 || id > 7) return CTN_ERR_ARG;
+    g_tile_override = id;
+    return CTN_OK;
+}
+
+int ctn_pw_stats_parts(int M, int R, int Kp) {
+    int tm, tn;
+    tile_dims(pick_tile(M, R, Kp), &tm, &tn);
+    return ctn_cdiv(R, tm) * ctn_cdiv(Kp, tn);
+}
 
 // Out[m] = op(W) . f(X[m]) (+ residual) ; see include/ctn_hip.h
 int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn, int K, int Kp, int trans_w,
@@ -379,29 +511,14 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0), "ctn_pw_gemm: incomplete prologue arguments");
     CTN_REQUIRE(!epi_part || epi_alpha, "ctn_pw_gemm: stats epilogue needs alpha");
     CTN_REQUIRE(!(trans_w && (pro_part || epi_part)), "ctn_pw_gemm: fused prologue/stats only with trans_w=0");
+    CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm: residual must be 16-byte aligned");
     PwArgs a{};
     a.W = W; a.X = X; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
-    a.tiles_r = ctn_cdiv(R, BM); a.tiles_c = ctn_cdiv(Kp, BN);
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
     a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * M)), block(NT);
-    hipStream_t st = (hipStream_t)stream;
-    if (trans_w) {
-        if (residual) hipLaunchKernelGGL((pw_gemm_kernel<1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_gemm_kernel<1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
-    } else if (pro_part) {
-        if (residual) hipLaunchKernelGGL((pw_gemm_kernel<0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_gemm_kernel<0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    } else if (epi_part) {
-        hipLaunchKernelGGL((pw_gemm_kernel<0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-    } else if (residual) {
-        hipLaunchKernelGGL((pw_gemm_kernel<0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-    } else if (relu_out) {
-        hipLaunchKernelGGL((pw_gemm_kernel<0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
-    } else {
-        hipLaunchKernelGGL((pw_gemm_kernel<0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
-    }
+    launch_fwd(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
+               (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_gemm");
     return CTN_OK;
 }
@@ -414,15 +531,18 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
     int rc = check_common("ctn_pw_dgrad_gln", W, dOut, dN, M, R, Cn, K, Kp);
     if (rc) return rc;
     CTN_REQUIRE(y && gamma && alpha && ms && sums_part, "ctn_pw_dgrad_gln: null pointer");
+    CTN_REQUIRE(aligned16(y), "ctn_pw_dgrad_gln: y must be 16-byte aligned");
     PwArgs a{};
     a.W = W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
-    a.tiles_r = ctn_cdiv(R, BM); a.tiles_c = ctn_cdiv(Kp, BN);
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * M)), block(NT);
-    hipLaunchKernelGGL((pw_gemm_kernel<1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, (hipStream_t)stream, a);
+    launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln");
     return CTN_OK;
 }
+
+}  // extern "C"
+
+extern "C" {
 
 static void wgrad_plan(int M, int R, int Cn, int Kp, int* chunk, int* chunks_per_m) {
     const int tiles = ctn_cdiv(R, BM) * ctn_cdiv(Cn, BN);

@@ -61,7 +61,7 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
     out = torch.empty((M, R, Kp), dtype=F32, device=X.device)
     epi_part = None
     if epi_alpha is not None:
-        epi_part = torch.empty((M, lib.ctn_pw_stats_parts(R, Kp), 2), dtype=F64, device=X.device)
+        epi_part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=X.device)
     pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
     _chk(W, X, pp, pg, pb, pa, residual, epi_alpha, ms_out)
     lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, int(trans_w),
@@ -217,7 +217,7 @@ class GlnBlock(torch.autograd.Function):
         dev = x.device
         st = _stream()
         # -- second 1x1: input gradient (+ gLN2 backward sums) and weight gradient
-        np2 = lib.ctn_pw_stats_parts(H, Kp)
+        np2 = lib.ctn_pw_stats_parts(M, H, Kp)
         dn2 = torch.empty((M, H, Kp), dtype=F32, device=dev)
         s2p = torch.empty((M, np2, 2), dtype=F64, device=dev)
         _chk(dout, x, h1, d)

@@ -48,17 +48,19 @@ int ctn_padded_frames(int K);               /* K rounded up to a multiple of 64 
  *     and written to pro_ms_out [M,2] when that is non-NULL.
  *   residual != NULL: TemporalBlock's "out + residual" (src/conv_tasnet.py:243).
  *   epi_part != NULL: also emits the partials of prelu(Out, epi_alpha) for the NEXT gLN,
- *     layout [M, ctn_pw_stats_parts(R,Kp), 2] fp64.
+ *     layout [M, ctn_pw_stats_parts(M,R,Kp), 2] fp64.
  *   relu_out != 0: Out = relu(.)  (encoder, src/conv_tasnet.py:120). */
 int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn, int K, int Kp, int trans_w,
                 const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
                 const float* pro_alpha, float* pro_ms_out,
                 const float* residual, const float* epi_alpha, double* epi_part, int relu_out, void* stream);
-int ctn_pw_stats_parts(int R, int Kp);
+int ctn_pw_stats_parts(int M, int R, int Kp);
+/* experiment / autotune hook: force GEMM tile id 0..4 (128x128, 128x64, 64x128, 64x64, 128x64 4x1 waves); -1 = heuristic */
+int ctn_tune_pw_tile(int id);
 
 /* dN[m] = W^T . dOut[m]   (W:[Cn,R] as stored by the forward layer, dOut:[M,Cn,Kp], dN:[M,R,Kp])
  * and, fused, the two sums gLN backward needs per utterance, as partials
- * sums_part [M, ctn_pw_stats_parts(R,Kp), 2] fp64:  S1 = sum gamma*dN,  S2 = sum gamma*dN*xhat,
+ * sums_part [M, ctn_pw_stats_parts(M,R,Kp), 2] fp64:  S1 = sum gamma*dN,  S2 = sum gamma*dN*xhat,
  * xhat = (prelu(y,alpha)-ms[m][0])*ms[m][1],  y:[M,R,Kp] the pre-activation input of that norm. */
 int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
                      const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,

@@ -27,7 +27,7 @@ def test_host_side_entry_points_without_gpu():
     assert ctn.lib.ctn_version() >= 100
     assert ctn.lib.ctn_padded_frames(3199) == 3200 and ctn.lib.ctn_padded_frames(64) == 64
     assert ctn.lib.ctn_padded_frames(1) == 64
-    assert ctn.lib.ctn_pw_stats_parts(512, 3200) == 4 * 25
+    assert ctn.lib.ctn_pw_stats_parts(8, 512, 3200) >= 100
     assert ctn.lib.ctn_pw_wgrad_workspace(8, 512, 256, 3200) % (512 * 256 * 4) == 0
     assert ctn.lib.ctn_dw_bwd_rows(3, 1) == 8 and ctn.lib.ctn_dw_bwd_rows(3, 0) == 3
     assert ctn.lib.ctn_sisnr_workspace(8, 2, 32000) == 8 * ctn.lib.ctn_sisnr_chunks(32000) * 12 * 8
