@@ -497,6 +497,34 @@ __global__ __launch_bounds__(NT) void reduce_mid_kernel(const float* __restrict_
     }
 }
 
+// Finish the per-(m,c) partials of dw_bwd<FUSED>:  pc [P+5, M, H] -> dD [H,P], dgamma2, dbeta2, dgamma1, dbeta1 [H],
+// dalpha2 [1].  Blocks 0..nb-2 do the per-channel sums over m (thread per (f,h)); the last block sums dalpha2.
+__global__ __launch_bounds__(NT) void dw_bwd_finalize_kernel(const float* __restrict__ pc, int P, int M, int H,
+                                                             float* __restrict__ dD, float* __restrict__ dg2,
+                                                             float* __restrict__ db2, float* __restrict__ dg1,
+                                                             float* __restrict__ db1, float* __restrict__ da2) {
+    __shared__ float red[NT / 64];
+    const size_t MH = (size_t)M * H;
+    if (blockIdx.x == gridDim.x - 1) {
+        float s = 0.f;
+        const float* src = pc + (size_t)(P + 4) * MH;
+        for (size_t i = threadIdx.x; i < MH; i += NT) s += src[i];
+        s = block_sum<float, NT>(s, red);
+        if (threadIdx.x == 0) da2[0] = s;
+        return;
+    }
+    const int o = blockIdx.x * NT + threadIdx.x;
+    if (o >= (P + 4) * H) return;
+    const int f = o / H, h = o % H;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += pc[(size_t)f * MH + (size_t)m * H + h];
+    if (f < P) dD[(size_t)h * P + f] = s;
+    else if (f == P) dg2[h] = s;
+    else if (f == P + 1) db2[h] = s;
+    else if (f == P + 2) dg1[h] = s;
+    else db1[h] = s;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -559,6 +587,17 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     if (fused) hipLaunchKernelGGL((dw_bwd_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dw_bwd_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
     CTN_CHECK_LAUNCH("ctn_dw_bwd");
+    return CTN_OK;
+}
+
+int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2,
+                        float* dgamma1, float* dbeta1, float* dalpha2, void* stream) {
+    CTN_REQUIRE(pc && dD && dgamma2 && dbeta2 && dgamma1 && dbeta1 && dalpha2, "ctn_dw_bwd_finalize: null pointer");
+    CTN_REQUIRE(P >= 1 && P <= MAXP && M > 0 && H > 0, "ctn_dw_bwd_finalize: bad sizes");
+    const unsigned nb = (unsigned)ctn_cdiv((P + 4) * H, NT) + 1;
+    hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, P, M, H, dD, dgamma2,
+                       dbeta2, dgamma1, dbeta1, dalpha2);
+    CTN_CHECK_LAUNCH("ctn_dw_bwd_finalize");
     return CTN_OK;
 }
 

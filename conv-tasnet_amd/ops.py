@@ -52,6 +52,20 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _sink(p):
+    """Destination view registered by FlatAdam: parameter gradients are then written straight into the flat
+    gradient buffer (one use of the parameter per step: overwrite, not accumulate) and autograd gets None."""
+    return getattr(p, "_ctn_grad_sink", None)
+
+
+def _emit(grad, sink):
+    """Return `grad` to autograd, or copy it into the sink and return None."""
+    if sink is None:
+        return grad
+    sink.copy_(grad.reshape(sink.shape))
+    return None
+
+
 # ---------------------------------------------------------------------------------------
 # thin typed wrappers (one per entry point actually used below)
 # ---------------------------------------------------------------------------------------
@@ -83,10 +97,10 @@ def _workspace(nbytes, device, tag):
     return buf
 
 
-def pw_wgrad(dOut, X, R, Cn, K, pro=None):
-    """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2])."""
+def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None):
+    """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2]).  out: optional destination."""
     M, _, Kp = X.shape
-    dW = torch.empty((R, Cn), dtype=F32, device=X.device)
+    dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
     nbytes = lib.ctn_pw_wgrad_workspace(M, R, Cn, Kp)
     ws = _workspace(nbytes, X.device, "wgrad")
     pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
@@ -96,9 +110,10 @@ def pw_wgrad(dOut, X, R, Cn, K, pro=None):
     return dW
 
 
-def reduce_mid(x, F, Mid, Inner):
-    out = torch.empty((F, Inner), dtype=F32, device=x.device)
-    _chk(x)
+def reduce_mid(x, F, Mid, Inner, out=None):
+    if out is None:
+        out = torch.empty((F, Inner), dtype=F32, device=x.device)
+    _chk(x, out)
     lib.call("ctn_reduce_mid", _p(x), _p(out), F, Mid, Inner, _stream())
     return out
 
@@ -164,6 +179,7 @@ class Frontend(torch.autograd.Function):
         x0, _ = pw_gemm(Wb, y0, B, N, K)
         ctx.save_for_backward(xcol, w, y0, mean0, rstd0, U, g0, Wb)
         ctx.K = K
+        ctx.sinks = (_sink(U), _sink(g0), _sink(b0), _sink(Wb))
         ctx.set_materialize_grads(False)
         return w, x0
 
@@ -177,12 +193,14 @@ class Frontend(torch.autograd.Function):
         if dx0 is None:
             dx0 = torch.zeros((M, B, Kp), dtype=F32, device=w.device)
         dx0 = _c(dx0)
+        sU, sg0, sb0, sWb = ctx.sinks
         dy0, _ = pw_gemm(Wb, dx0, N, B, K, trans_w=True)
-        dWb = pw_wgrad(dx0, y0, B, N, K)
+        dWb = pw_wgrad(dx0, y0, B, N, K, out=sWb)
         add = None if dw_dec is None else _c(dw_dec)
         g, dg0, db0, _ = cln_bwd(dy0, w, mean0, rstd0, g0, None, K, add=add, relu_ref=w)
-        dU = pw_wgrad(g, xcol, N, L, K)
-        return None, dU.view(N, 1, L), dg0.view(1, N, 1), db0.view(1, N, 1), dWb.view(B, N, 1)
+        dU = pw_wgrad(g, xcol, N, L, K, out=sU)
+        return (None, None if sU is not None else dU.view(N, 1, L), _emit(dg0.view(1, N, 1), sg0),
+                _emit(db0.view(1, N, 1), sb0), None if sWb is not None else dWb.view(B, N, 1))
 
 
 # ---------------------------------------------------------------------------------------
@@ -204,11 +222,14 @@ class GlnBlock(torch.autograd.Function):
         out, _ = pw_gemm(w2, d, B, H, K, pro=(st2, g2, b2, a2), residual=x, ms_out=ms2)
         ctx.save_for_backward(x, h1, d, ms1, ms2, w1, a1, g1, b1, D, a2, g2, b2, w2)
         ctx.cfg = (K, dilation, causal)
+        ctx.sinks = tuple(_sink(p) for p in (w1, a1, g1, b1, D, a2, g2, b2, w2))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, h1, d, ms1, ms2, w1, a1, g1, b1, D, a2, g2, b2, w2 = ctx.saved_tensors
+        sinks = ctx.sinks
+        direct = all(t is not None for t in sinks)
         K, dilation, causal = ctx.cfg
         dout = _c(dout)
         M, B, Kp = x.shape
@@ -222,7 +243,7 @@ class GlnBlock(torch.autograd.Function):
         s2p = torch.empty((M, np2, 2), dtype=F64, device=dev)
         _chk(dout, x, h1, d)
         lib.call("ctn_pw_dgrad_gln", _p(w2), _p(dout), _p(dn2), M, H, B, K, Kp, _p(d), _p(g2), _p(a2), _p(ms2), _p(s2p), st)
-        dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2))
+        dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2), out=sinks[8] if direct else None)
         # -- gLN2 <- PReLU2 <- depthwise <- gLN1 output, one pass
         Fr = lib.ctn_dw_bwd_rows(P, 1)
         pc = torch.empty((Fr, M, H), dtype=F32, device=dev)
@@ -230,18 +251,25 @@ class GlnBlock(torch.autograd.Function):
         dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
         lib.call("ctn_dw_bwd", _p(dn2), _p(d), _p(h1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 1,
                  _p(g1), _p(b1), _p(a1), _p(ms1), _p(g2), _p(a2), _p(ms2), _p(s2p), np2, _p(pc), _p(s1p), st)
-        red = reduce_mid(pc, Fr, M, H)
-        dD = red[:P].t().contiguous().view(H, 1, P)
-        da2 = reduce_mid(red[P + 4], 1, H, 1).view(1)
+        if direct:
+            _, s_a1, s_g1, s_b1, s_D, s_a2, s_g2, s_b2, _ = sinks
+            dD, dg2, db2, dg1, db1, da2, da1 = s_D, s_g2, s_b2, s_g1, s_b1, s_a2, s_a1
+        else:
+            dD = torch.empty((H, 1, P), dtype=F32, device=dev)
+            dg2, db2, dg1, db1 = (torch.empty((1, H, 1), dtype=F32, device=dev) for _ in range(4))
+            da2 = torch.empty((1,), dtype=F32, device=dev)
+            da1 = torch.empty((1,), dtype=F32, device=dev)
+        lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), st)
         # -- gLN1 + PReLU1 backward, in place on dn1
         da1p = torch.empty((M * H,), dtype=F32, device=dev)
         lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), st)
-        da1 = reduce_mid(da1p, 1, M * H, 1).view(1)
+        reduce_mid(da1p, 1, M * H, 1, out=da1)
         # -- first 1x1
         dx, _ = pw_gemm(w1, dn1, B, H, K, trans_w=True, residual=dout)
-        dW1 = pw_wgrad(dn1, x, H, B, K)
-        return (dx, dW1.view(H, B, 1), da1, red[P + 2].view(1, H, 1), red[P + 3].view(1, H, 1), dD, da2,
-                red[P].view(1, H, 1), red[P + 1].view(1, H, 1), dW2.view(B, H, 1), None, None, None)
+        dW1 = pw_wgrad(dn1, x, H, B, K, out=sinks[0] if direct else None)
+        if direct:
+            return (dx,) + (None,) * 12
+        return (dx, dW1.view(H, B, 1), da1, dg1, db1, dD, da2, dg2, db2, dW2.view(B, H, 1), None, None, None)
 
 
 # ---------------------------------------------------------------------------------------
@@ -262,6 +290,7 @@ class ClnBlock(torch.autograd.Function):
         out, _ = pw_gemm(w2, n2, B, H, K, residual=x)
         ctx.save_for_backward(x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2)
         ctx.cfg = (K, dilation, causal)
+        ctx.sinks = tuple(_sink(p) for p in (w1, a1, g1, b1, D, a2, g2, b2, w2))
         return out
 
     @staticmethod
@@ -285,8 +314,10 @@ class ClnBlock(torch.autograd.Function):
         dh1, dg1, db1, da1 = cln_bwd(dn1, h1, mean1, rstd1, g1, a1, K)
         dx, _ = pw_gemm(w1, dh1, B, H, K, trans_w=True, residual=dout)
         dW1 = pw_wgrad(dh1, x, H, B, K)
-        return (dx, dW1.view(H, B, 1), da1, dg1.view(1, H, 1), db1.view(1, H, 1), dD, da2,
-                dg2.view(1, H, 1), db2.view(1, H, 1), dW2.view(B, H, 1), None, None, None)
+        sk = ctx.sinks
+        return (dx, _emit(dW1.view(H, B, 1), sk[0]), _emit(da1, sk[1]), _emit(dg1.view(1, H, 1), sk[2]),
+                _emit(db1.view(1, H, 1), sk[3]), _emit(dD, sk[4]), _emit(da2, sk[5]), _emit(dg2.view(1, H, 1), sk[6]),
+                _emit(db2.view(1, H, 1), sk[7]), _emit(dW2.view(B, H, 1), sk[8]), None, None, None)
 
 
 # ---------------------------------------------------------------------------------------
@@ -321,6 +352,7 @@ class Backend(torch.autograd.Function):
         lib.call("ctn_ola", _p(fr), _p(est), M * C, T, L, L, K, Kp, _stream())
         ctx.save_for_backward(x, w, score, sw, Wm, V)
         ctx.cfg = (K, T, C, softmax)
+        ctx.sinks = (_sink(Wm), _sink(V))
         return est
 
     @staticmethod
@@ -337,13 +369,15 @@ class Backend(torch.autograd.Function):
         _chk(dest)
         lib.call("ctn_unfold", _p(dest), _p(dfr), M * C, T, L, L, K, Kp, _stream())
         dsw, _ = pw_gemm(V, dfr, N, L, K, trans_w=True)                 # [M*C, N, Kp]
-        dV = pw_wgrad(dfr, sw.view(M * C, N, Kp), L, N, K)
+        sWm, sV = ctx.sinks
+        dV = pw_wgrad(dfr, sw.view(M * C, N, Kp), L, N, K, out=sV)
         dw = torch.empty((M, N, Kp), dtype=F32, device=dev)
         lib.call("ctn_mask_apply_bwd", _p(dsw), _p(score), _p(w), _p(dsw), _p(dw), M, C, N, Kp, int(softmax), _stream())
         dscore = dsw.view(M, CN, Kp)
         dx, _ = pw_gemm(Wm, dscore, B, CN, K, trans_w=True)
-        dWm = pw_wgrad(dscore, x, CN, B, K)
-        return dx, dw, dWm.view(CN, B, 1), dV, None, None, None, None
+        dWm = pw_wgrad(dscore, x, CN, B, K, out=sWm)
+        return (dx, dw, None if sWm is not None else dWm.view(CN, B, 1), None if sV is not None else dV,
+                None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------

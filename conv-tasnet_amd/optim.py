@@ -16,12 +16,16 @@ def _round4(n):
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, direct_grads=True):
         if weight_decay != 0:
             raise NotImplementedError("FlatAdam: weight_decay != 0 is not on the hot path (reference uses l2 = 0)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0))
         if len(self.param_groups) != 1:
             raise ValueError("FlatAdam takes a single parameter group")
+        # direct_grads: the HIP backward stages write each parameter gradient straight into flat_grads (no
+        # AccumulateGrad add per tensor).  Semantics: a backward pass OVERWRITES the gradient, so accumulate over
+        # several backward calls only with direct_grads=False.
+        self.direct_grads = bool(direct_grads)
         self._flatten()
         self._step = 0
         self.last_total_norm = None
@@ -51,6 +55,8 @@ class FlatAdam(torch.optim.Optimizer):
             self.flat_params[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_params[o:o + n].view(p.shape)
             p.grad = self.flat_grads[o:o + n].view(p.shape)
+            if self.direct_grads:
+                p._ctn_grad_sink = p.grad
 
     def _grad_views_intact(self):
         base = self.flat_grads.data_ptr()
