@@ -19,8 +19,10 @@ namespace {
 constexpr int NT = 256;
 constexpr int ROWS = 4;          // one wave per row
 constexpr int MAXP = 8;          // max depthwise kernel size supported
-constexpr int FWD_BUF = 3584;    // floats of LDS per wave (forward): 56 KiB / block
-constexpr int BWD_BUF = 1792;    // floats per wave per array (backward, two arrays): 56 KiB / block
+// LDS floats per wave for the row segment (+halo).  Small buffers when the receptive field is short (more
+// workgroups per CU in flight = more HBM requests outstanding), large ones when the halo would dominate.
+constexpr int FWD_BUF_S = 1024, FWD_BUF_L = 3584;    // forward: 16 / 56 KiB per workgroup
+constexpr int BWD_BUF_S = 768, BWD_BUF_L = 1792;     // backward (two arrays): 24 / 56 KiB per workgroup
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ int floor4(int v) { return (v >> 2) << 2; }  // arithmetic shift: floors negatives
@@ -36,7 +38,7 @@ struct DwFwdArgs {
     const float* epi_alpha; double* epi_part;   // [M, H, 2]
 };
 
-template <bool PRO, bool EPI>
+template <bool PRO, bool EPI, int FWD_BUF>
 __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float buf[ROWS][FWD_BUF];
     __shared__ double red[NT / 64];
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             }
             *reinterpret_cast<float4*>(L + j) = v;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();   // the LDS patch is private to this wave; DS ops of one wave retire in order
         for (int k = k0 + lane; k < kend; k += 64) {
             const int idx = k - base - a.padl;
             float acc = 0.f;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             }
             if (live) z[k] = acc;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     if constexpr (EPI) {
         const double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
@@ -136,7 +138,7 @@ struct DwBwdArgs {
     double* sums1_part;    // [M, H, 2]
 };
 
-template <bool FUSED>
+template <bool FUSED, int BWD_BUF>
 __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float bufA[ROWS][BWD_BUF];  // dd
     __shared__ __attribute__((aligned(16))) float bufB[ROWS][BWD_BUF];  // xh1 (FUSED) or x (PLAIN)
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 *reinterpret_cast<float4*>(LB + j) = v;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();   // wave-private LDS patches
         for (int k = k0 + lane; k < kend; k += 64) {
             // input gradient: transposed taps
             float acc = 0.f;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
             }
             if (live) dn1[k] = acc;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     const size_t MH = (size_t)a.M * a.H, rc = (size_t)m * a.H + c;
 #pragma unroll
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(NT) void cln_bwd_params_kernel(const float* __restr
     }
 }
 
-// out[f][i] = sum_mid in[f][mid][i]   (fixed order).  mode 0: thread per output; mode 1: wave per output.
+// out[f][i] = sum_mid in[f][mid][i]   (fixed order).  mode 0: thread per output; mode 1: workgroup per output.
 __global__ __launch_bounds__(NT) void reduce_mid_kernel(const float* __restrict__ in, int F, int Mid, int Inner,
                                                         float* __restrict__ out, int wave_mode) {
     if (!wave_mode) {
@@ -486,14 +488,14 @@ __global__ __launch_bounds__(NT) void reduce_mid_kernel(const float* __restrict_
         float s = 0.f;
         for (int r = 0; r < Mid; ++r) s += in[((size_t)f * Mid + r) * Inner + i];
         out[o] = s;
-    } else {
-        const long long o = (long long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-        if (o >= (long long)F * Inner) return;
-        const int f = (int)(o / Inner), i = (int)(o % Inner), lane = threadIdx.x & 63;
+    } else {                                        // one workgroup per output
+        __shared__ float red[NT / 64];
+        const long long o = blockIdx.x;
+        const int f = (int)(o / Inner), i = (int)(o % Inner);
         float s = 0.f;
-        for (int r = lane; r < Mid; r += 64) s += in[((size_t)f * Mid + r) * Inner + i];
-        s = wave_sum(s);
-        if (lane == 0) out[o] = s;
+        for (int r = threadIdx.x; r < Mid; r += NT) s += in[((size_t)f * Mid + r) * Inner + i];
+        s = block_sum<float, NT>(s, red);
+        if (threadIdx.x == 0) out[o] = s;
     }
 }
 
@@ -540,7 +542,8 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
     CTN_REQUIRE(aligned16(Y) && aligned16(Z), "ctn_dw_fwd: pointers must be 16-byte aligned");
     const int halo = (P - 1) * dilation;
     CTN_REQUIRE(causal || halo % 2 == 0, "ctn_dw_fwd: non-causal 'same' padding needs (P-1)*dilation even");
-    const int seg = ((FWD_BUF - halo - 8) / 64) * 64;
+    const bool small = halo <= 192;
+    const int seg = (((small ? FWD_BUF_S : FWD_BUF_L) - halo - 8) / 64) * 64;
     CTN_REQUIRE(seg >= 64, "ctn_dw_fwd: receptive field (P-1)*dilation=%d too large", halo);
     CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0), "ctn_dw_fwd: incomplete prologue arguments");
     CTN_REQUIRE(!epi_part || epi_alpha, "ctn_dw_fwd: stats epilogue needs alpha");
@@ -551,10 +554,16 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
-    if (pro_part && epi_part) hipLaunchKernelGGL((dw_fwd_kernel<true, true>), grid, block, 0, st, a);
-    else if (pro_part) hipLaunchKernelGGL((dw_fwd_kernel<true, false>), grid, block, 0, st, a);
-    else if (epi_part) hipLaunchKernelGGL((dw_fwd_kernel<false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((dw_fwd_kernel<false, false>), grid, block, 0, st, a);
+#define CTN_DW_FWD(P_, E_)                                                                           \
+    do {                                                                                             \
+        if (small) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_S>), grid, block, 0, st, a);    \
+        else hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_L>), grid, block, 0, st, a);          \
+    } while (0)
+    if (pro_part && epi_part) CTN_DW_FWD(true, true);
+    else if (pro_part) CTN_DW_FWD(true, false);
+    else if (epi_part) CTN_DW_FWD(false, true);
+    else CTN_DW_FWD(false, false);
+#undef CTN_DW_FWD
     CTN_CHECK_LAUNCH("ctn_dw_fwd");
     return CTN_OK;
 }
@@ -573,7 +582,8 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     CTN_REQUIRE(aligned16(dN2) && aligned16(Y1) && aligned16(dN1) && (!fused || aligned16(Dz)), "ctn_dw_bwd: alignment");
     const int halo = (P - 1) * dilation;
     CTN_REQUIRE(causal || halo % 2 == 0, "ctn_dw_bwd: non-causal 'same' padding needs (P-1)*dilation even");
-    const int seg = ((BWD_BUF - halo - 8) / 64) * 64;
+    const bool small = halo <= 128;
+    const int seg = (((small ? BWD_BUF_S : BWD_BUF_L) - halo - 8) / 64) * 64;
     CTN_REQUIRE(seg >= 64, "ctn_dw_bwd: receptive field (P-1)*dilation=%d too large", halo);
     if (fused)
         CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && sums1_part,
@@ -584,8 +594,14 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     a.g1 = g1; a.b1 = b1; a.a1 = a1; a.ms1 = ms1; a.g2 = g2; a.a2 = a2; a.ms2 = ms2;
     a.sums2_part = sums2_part; a.sums2_nparts = sums2_nparts; a.pc = pc; a.sums1_part = sums1_part;
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
-    if (fused) hipLaunchKernelGGL((dw_bwd_kernel<true>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((dw_bwd_kernel<false>), grid, block, 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (fused) {
+        if (small) hipLaunchKernelGGL((dw_bwd_kernel<true, BWD_BUF_S>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((dw_bwd_kernel<true, BWD_BUF_L>), grid, block, 0, st, a);
+    } else {
+        if (small) hipLaunchKernelGGL((dw_bwd_kernel<false, BWD_BUF_S>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((dw_bwd_kernel<false, BWD_BUF_L>), grid, block, 0, st, a);
+    }
     CTN_CHECK_LAUNCH("ctn_dw_bwd");
     return CTN_OK;
 }
@@ -649,7 +665,7 @@ int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void*
     CTN_REQUIRE(in && out && F > 0 && Mid > 0 && Inner > 0, "ctn_reduce_mid: bad arguments");
     const long long n = (long long)F * Inner;
     const int wave_mode = (Mid >= 256 && n <= 4096) ? 1 : 0;
-    const unsigned blocks = wave_mode ? (unsigned)ctn_cdivll(n, NT / 64) : (unsigned)ctn_cdivll(n, NT);
+    const unsigned blocks = wave_mode ? (unsigned)n : (unsigned)ctn_cdivll(n, NT);
     hipLaunchKernelGGL(reduce_mid_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, in, F, Mid, Inner, out, wave_mode);
     CTN_CHECK_LAUNCH("ctn_reduce_mid");
     return CTN_OK;
