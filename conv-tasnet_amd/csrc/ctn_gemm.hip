@@ -68,6 +68,86 @@ struct PwArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// ---- shared epilogue (fp32-MFMA and split-bf16 kernels: the 32x32 C/D register map is dtype-independent) ----
+// Each wave transposes its accumulators through a private LDS patch (32 rows at a time) so that global traffic
+// is 16 bytes per lane along frames instead of 64 dword accesses; residual / ReLU / PReLU-statistics / gLN-backward
+// sums are applied on the float4s.  C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+template <typename TL, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL::MT][TL::NTL], float* smem, double* red,
+                                              int m, int rt, int ct) {
+    constexpr int MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, TM = TL::TM, TN = TL::TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WGN, wn = wave % TL::WGN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int r0 = rt * TM, c0 = ct * TN;
+    float* __restrict__ Om = a.Out + (size_t)m * a.R * a.Kp;
+    float e_alpha = 0.f, b_mean = 0.f, b_rstd = 1.f;
+    if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
+    if constexpr (EPI == EPI_GLN_BWD) {
+        e_alpha = a.bwd_alpha[0];
+        b_mean = a.bwd_ms[2 * m];
+        b_rstd = a.bwd_ms[2 * m + 1];
+    }
+    constexpr int LST = TL::LDS_ST;
+    constexpr int C4 = WN / 4;              // lanes per staged row
+    constexpr int RPP = 64 / C4;            // rows per pass
+    float* const stage = smem + wave * 32 * LST;
+    float s1 = 0.f, s2 = 0.f;
+    const size_t mbase = (size_t)m * a.R * a.Kp;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[((e & 3) + 8 * (e >> 2) + 4 * lhi) * LST + nt * 32 + l31] = acc[mt][nt][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 32 / RPP; ++p) {
+            const int rl = p * RPP + lane / C4, cl = (lane % C4) * 4;
+            const int r = r0 + wm * WM + mt * 32 + rl, k = c0 + wn * WN + cl;
+            float4 v = *reinterpret_cast<const float4*>(stage + rl * LST + cl);
+            if (r < a.R && k < a.Kp) {
+                const size_t off = (size_t)r * a.Kp + k;
+                if constexpr (EPI == EPI_RESIDUAL) {
+                    const float4 q = ld4(a.residual + mbase + off);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                if constexpr (EPI == EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if constexpr (EPI == EPI_PRELU_STATS) {
+                    const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
+                    const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
+                    s1 += (p0 + p1) + (p2 + p3);
+                    s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+                }
+                if constexpr (EPI == EPI_GLN_BWD) {
+                    const float4 y = ld4(a.bwd_y + mbase + off);
+                    const float g = a.bwd_gamma[r];
+                    const float t0 = g * v.x, t1 = g * v.y, t2 = g * v.z, t3 = g * v.w;
+                    const float x0 = (prelu_f(y.x, e_alpha) - b_mean) * b_rstd, x1 = (prelu_f(y.y, e_alpha) - b_mean) * b_rstd;
+                    const float x2 = (prelu_f(y.z, e_alpha) - b_mean) * b_rstd, x3 = (prelu_f(y.w, e_alpha) - b_mean) * b_rstd;
+                    s1 += (t0 + t1) + (t2 + t3);
+                    s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
+                }
+                *reinterpret_cast<float4*>(Om + off) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
+        const double d1 = block_sum<double, NT>((double)s1, red);
+        const double d2 = block_sum<double, NT>((double)s2, red);
+        if (tid == 0) {
+            double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
+                          ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 2;
+            dst[0] = d1;
+            dst[1] = d2;
+        }
+    }
+}
+
 template <typename TL, int TRANS_W, int PRO, int EPI>
 __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
     constexpr int TM = TL::TM, TN = TL::TN, LDA = TL::LDA, LDB = TL::LDB, MT = TL::MT, NTL = TL::NTL;
@@ -210,73 +290,242 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
         }
     }
 
-    // ---- epilogue: each wave transposes its accumulators through a private LDS patch (32 rows at a
-    // time) so that global traffic is 16 bytes per lane along frames instead of 64 dword accesses.
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    float e_alpha = 0.f, b_mean = 0.f, b_rstd = 1.f;
-    if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
-    if constexpr (EPI == EPI_GLN_BWD) {
-        e_alpha = a.bwd_alpha[0];
-        b_mean = a.bwd_ms[2 * m];
-        b_rstd = a.bwd_ms[2 * m + 1];
+    gemm_epilogue<TL, EPI>(a, acc, smem, red, m, rt, ct);
+}
+
+// ===========================================================================================
+// Split-bf16 ("x6") GEMMs: fp32-accurate products on the bf16 matrix cores.
+//
+// Every fp32 operand is split exactly into three bf16 pieces  a = a1 + a2 + a3  (8 significand bits each,
+// the subtractions are exact in fp32), and a.b is formed from the six piece-products whose weight is
+// >= 2^-16:  a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1);  the dropped terms are <= 2^-24 |ab|, i.e. below
+// fp32 rounding.  Each piece-product is exact in the fp32 accumulator (8x8-bit significands).  The leading term
+// and the five small ones go to separate accumulators that are added once at the end.
+// v_mfma_f32_32x32x16_bf16 retires 16 contraction steps in 32 cycles, v_mfma_f32_32x32x2_f32 2 steps in 64:
+// six bf16 MFMAs replace eight fp32 MFMAs at a quarter of their cycles each -> 2.7x the fp32-MFMA rate.
+//
+// Weights arrive pre-split (ctn_split_bf16: [3][R][Cnp] bf16, contraction contiguous, Cnp = Cn padded to 32
+// with zeros); activations are split while they are staged global -> LDS (after the optional PReLU+gLN
+// prologue).  A fragments are 16-byte row reads; B fragments (contraction = channels, strided in memory) come
+// out of ds_read_b64_tr_b16, the hardware transpose read, from channel-major LDS planes.
+// ===========================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int XK = 32;            // channels per k-tile (two 16-deep MFMA steps)
+constexpr int XPA = 40;           // A-plane row pitch in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
+
+template <typename TL>
+struct X6 {
+    static constexpr int PB = TL::TN + 32;                          // B-plane row pitch in bf16 (TN*2 + 64 B)
+    static constexpr int A_ELEMS = 3 * TL::TM * XPA;                // bf16 elements
+    static constexpr int B_ELEMS = 3 * XK * PB;
+    static constexpr int MAIN_BYTES = (A_ELEMS + B_ELEMS) * 2;
+    static constexpr int STAGE_BYTES = TL::STAGE_FLOATS * 4;
+    static constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+};
+
+struct Bf3 { __bf16 a, b, c; };
+__device__ __forceinline__ Bf3 split3(float v) {
+    Bf3 r;
+    r.a = (__bf16)v;
+    const float r1 = v - (float)r.a;
+    r.b = (__bf16)r1;
+    r.c = (__bf16)(r1 - (float)r.b);
+    return r;
+}
+// four consecutive fp32 -> the three bf16x4 pieces
+__device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2, bf16x4& q3) {
+    const Bf3 s0 = split3(v.x), s1 = split3(v.y), s2 = split3(v.z), s3 = split3(v.w);
+    q1 = bf16x4{s0.a, s1.a, s2.a, s3.a};
+    q2 = bf16x4{s0.b, s1.b, s2.b, s3.b};
+    q3 = bf16x4{s0.c, s1.c, s2.c, s3.c};
+}
+
+struct X6Args {
+    PwArgs p;              // W unused
+    const __bf16* Wp;      // [3][R][Cnp]
+    int Cnp;
+};
+
+template <typename TL, int PRO, int EPI>
+__global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
+    const PwArgs& a = xa.p;
+    constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN;
+    constexpr int PB = X6<TL>::PB;
+    constexpr int A_L = TM / 64;                  // 16-byte loads per thread per plane (4 threads per row of 32 k)
+    constexpr int B_L = TN / 32;                  // float4 loads per thread (TN/4 threads per channel row)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[X6<TL>::SMEM_BYTES];
+    __shared__ double red[NT / 64];
+    __bf16* const Ap = reinterpret_cast<__bf16*>(smem_raw);                  // [3][TM][XPA]
+    __bf16* const Bp = Ap + X6<TL>::A_ELEMS;                                 // [3][XK][PB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WGN, wn = wave % TL::WGN;
+    int bid = blockIdx.x;
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c;
+    const int m = bid / a.tiles_c;
+    const int r0 = rt * TM, c0 = ct * TN;
+    const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        finalize_stats<NT>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts,
+                           (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
+        p_alpha = a.pro_alpha[0];
+        if (a.pro_ms_out != nullptr && rt == 0 && ct == 0 && tid == 0) {
+            a.pro_ms_out[2 * m] = p_mean;
+            a.pro_ms_out[2 * m + 1] = p_rstd;
+        }
     }
-    constexpr int LST = TL::LDS_ST;
-    constexpr int C4 = WN / 4;              // lanes per staged row
-    constexpr int RPP = 64 / C4;            // rows per pass
-    float* const stage = smem + wave * 32 * LST;
-    float s1 = 0.f, s2 = 0.f;
-    const size_t mbase = (size_t)m * a.R * a.Kp;
+    const int nk = xa.Cnp / XK;
+    const size_t plane = (size_t)a.R * xa.Cnp;
+
+    // loop-invariant per-thread source pointers / predicates; only the k-tile offset changes per iteration
+    const __bf16* a_src[A_L];
+    bool a_ok[A_L];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int j = 0; j < A_L; ++j) {
+        const int r = r0 + (tid >> 2) + 64 * j;
+        a_ok[j] = r < a.R;
+        a_src[j] = xa.Wp + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (tid & 3) * 8;
+    }
+    const float* b_src[B_L];
+    int b_ch[B_L];
+    const int b_k = c0 + (tid % (TN / 4)) * 4;
+    const bool b_kok = b_k < a.Kp;
 #pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
+    for (int j = 0; j < B_L; ++j) {
+        b_ch[j] = tid / (TN / 4) + (1024 / TN) * j;
+        b_src[j] = Xm + (size_t)b_ch[j] * a.Kp + (b_kok ? b_k : 0);
+    }
+    const size_t b_step = (size_t)XK * a.Kp;
+    auto load_regs = [&](int kt, uint4 (&ra)[3][A_L], float4 (&rb)[B_L]) {
+        const int kc = kt * XK;
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                stage[((e & 3) + 8 * (e >> 2) + 4 * lhi) * LST + nt * 32 + l31] = acc[mt][nt][e];
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < A_L; ++j) {
 #pragma unroll
-        for (int p = 0; p < 32 / RPP; ++p) {
-            const int rl = p * RPP + lane / C4, cl = (lane % C4) * 4;
-            const int r = r0 + wm * WM + mt * 32 + rl, k = c0 + wn * WN + cl;
-            float4 v = *reinterpret_cast<const float4*>(stage + rl * LST + cl);
-            if (r < a.R && k < a.Kp) {
-                const size_t off = (size_t)r * a.Kp + k;
-                if constexpr (EPI == EPI_RESIDUAL) {
-                    const float4 q = ld4(a.residual + mbase + off);
-                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-                }
-                if constexpr (EPI == EPI_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                if constexpr (EPI == EPI_PRELU_STATS) {
-                    const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
-                    const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
-                    s1 += (p0 + p1) + (p2 + p3);
-                    s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
-                }
-                if constexpr (EPI == EPI_GLN_BWD) {
-                    const float4 y = ld4(a.bwd_y + mbase + off);
-                    const float g = a.bwd_gamma[r];
-                    const float t0 = g * v.x, t1 = g * v.y, t2 = g * v.z, t3 = g * v.w;
-                    const float x0 = (prelu_f(y.x, e_alpha) - b_mean) * b_rstd, x1 = (prelu_f(y.y, e_alpha) - b_mean) * b_rstd;
-                    const float x2 = (prelu_f(y.z, e_alpha) - b_mean) * b_rstd, x3 = (prelu_f(y.w, e_alpha) - b_mean) * b_rstd;
-                    s1 += (t0 + t1) + (t2 + t3);
-                    s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
-                }
-                *reinterpret_cast<float4*>(Om + off) = v;
+            for (int p = 0; p < 3; ++p) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (a_ok[j]) v = *reinterpret_cast<const uint4*>(a_src[j] + p * plane + kc);
+                ra[p][j] = v;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
-        const double d1 = block_sum<double, NT>((double)s1, red);
-        const double d2 = block_sum<double, NT>((double)s2, red);
-        if (tid == 0) {
-            double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
-                          ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 2;
-            dst[0] = d1;
-            dst[1] = d2;
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            const int i = kc + b_ch[j];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < a.Cn && b_kok) {
+                v = ld4(b_src[j] + (size_t)kt * b_step);
+                if constexpr (PRO == PRO_PRELU_NORM) {
+                    const int k = b_k;
+                    const float g = a.pro_gamma[i], b = a.pro_beta[i];
+                    v.x = (k + 0 < a.K) ? g * ((prelu_f(v.x, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                    v.y = (k + 1 < a.K) ? g * ((prelu_f(v.y, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                    v.z = (k + 2 < a.K) ? g * ((prelu_f(v.z, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                    v.w = (k + 3 < a.K) ? g * ((prelu_f(v.w, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                }
+            }
+            rb[j] = v;
         }
+    };
+    auto write_lds = [&](const uint4 (&ra)[3][A_L], const float4 (&rb)[B_L]) {
+#pragma unroll
+        for (int j = 0; j < A_L; ++j) {
+            const int r = (tid >> 2) + 64 * j, c = (tid & 3) * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = ra[p][j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            const int i = tid / (TN / 4) + (1024 / TN) * j, k = (tid % (TN / 4)) * 4;
+            bf16x4 q1, q2, q3;
+            split3x4(rb[j], q1, q2, q3);
+            *reinterpret_cast<bf16x4*>(Bp + (0 * XK + i) * PB + k) = q1;
+            *reinterpret_cast<bf16x4*>(Bp + (1 * XK + i) * PB + k) = q2;
+            *reinterpret_cast<bf16x4*>(Bp + (2 * XK + i) * PB + k) = q3;
+        }
+    };
+
+    f32x16 hi[MT][NTL], lo[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // transpose-read lane map: 16-lane group g = lane>>4 covers frames 16*(g&1).. of the 32-frame MFMA tile and
+    // channels 8*(g>>1)..; lane 4q+p of a group addresses channel row q, frames 4p..4p+3.
+    const int tr_q = (lane >> 2) & 3, tr_f = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    typedef bf16x4 __attribute__((address_space(3))) * lds_b4;
+
+    auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MT][3], bfr[NTL][3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * TM + wm * WM + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const __bf16* base = Bp + (p * XK + ks * 16 + lhi * 8 + tr_q) * PB + wn * WN + j * 32 + tr_f;
+                const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base));
+                const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base + 4 * PB));
+                bfr[j][p] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], lo[i][j], 0, 0, 0);
+                lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], lo[i][j], 0, 0, 0);
+                hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], hi[i][j], 0, 0, 0);
+            }
+    }
+    };
+
+    // register prefetch (distance 1), one LDS buffer, two barriers per k-tile.  A distance-2 variant measured slower
+    // (register pressure), see profiles/README.md.
+    uint4 pa[3][A_L];
+    float4 pb[B_L];
+    load_regs(0, pa, pb);
+    for (int kt = 0; kt < nk; ++kt) {
+        write_lds(pa, pb);
+        __syncthreads();
+        if (kt + 1 < nk) load_regs(kt + 1, pa, pb);
+        compute();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hi[i][j][e] += lo[i][j][e];
+    gemm_epilogue<TL, EPI>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+}
+
+// W [rows, cols] fp32 -> planes [3][R][Cnp] bf16 with R x Cn = (transpose ? cols x rows : rows x cols); zero pad to Cnp
+__global__ __launch_bounds__(NT) void split_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ P, int rows,
+                                                        int cols, int transpose, int R, int Cn, int Cnp) {
+    const long long n = (long long)R * Cnp;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int r = (int)(i / Cnp), c = (int)(i % Cnp);
+        float v = 0.f;
+        if (c < Cn) v = transpose ? W[(size_t)c * cols + r] : W[(size_t)r * cols + c];
+        const Bf3 q = split3(v);
+        P[i] = q.a;
+        P[n + i] = q.b;
+        P[2 * n + i] = q.c;
     }
 }
 
@@ -398,6 +647,126 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
             for (int nt = 0; nt < 2; ++nt) {
                 const int c = c0 + wn * 64 + nt * 32 + l31;
                 if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = acc[mt][nt][e];
+            }
+        }
+}
+
+// Split-bf16 weight gradient: both operands are activations (contraction = frames, contiguous in memory), so both
+// are split while staged and both fragments are plain 16-byte row reads.  128x128 (o x i) tile, 32 frames per k-tile.
+template <int PRO>
+__global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[3 * BM * XPA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bp[3 * BN * XPA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c; bid /= a.tiles_c;
+    const int sp = bid;
+    const int m = sp / a.chunks_per_m, ch = sp % a.chunks_per_m;
+    const int kb = ch * a.chunk;
+    const int ke = min(kb + a.chunk, a.Kp);
+    const int r0 = rt * BM, c0 = ct * BN;
+    const float* __restrict__ Gm = a.dOut + (size_t)m * a.R * a.Kp;
+    const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        p_mean = a.pro_ms[2 * m];
+        p_rstd = a.pro_ms[2 * m + 1];
+        p_alpha = a.pro_alpha[0];
+    }
+    // staging map: 8 threads per row (32 frames = 8 float4), 32 rows per pass, 4 passes for 128 rows
+    float4 ra[4], rb[4];
+    const int nk = (ke - kb + XK - 1) / XK;
+    auto load_regs = [&](int kt) {
+        const int k = kb + kt * XK + (tid & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (tid >> 3) + 32 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < a.R && k < ke) v = ld4(Gm + (size_t)(r0 + row) * a.Kp + k);
+            ra[j] = v;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = c0 + row;
+            if (c < a.Cn && k < ke) {
+                x = ld4(Xm + (size_t)c * a.Kp + k);
+                if constexpr (PRO == PRO_PRELU_NORM) {
+                    const float g = a.pro_gamma[c], b = a.pro_beta[c];
+                    x.x = (k + 0 < a.K) ? g * ((prelu_f(x.x, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                    x.y = (k + 1 < a.K) ? g * ((prelu_f(x.y, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                    x.z = (k + 2 < a.K) ? g * ((prelu_f(x.z, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                    x.w = (k + 3 < a.K) ? g * ((prelu_f(x.w, p_alpha) - p_mean) * p_rstd) + b : 0.f;
+                }
+            }
+            rb[j] = x;
+        }
+    };
+    auto write_one = [&](__bf16* P, int row, int kq, const float4& v) {
+        bf16x4 q1, q2, q3;
+        split3x4(v, q1, q2, q3);
+        *reinterpret_cast<bf16x4*>(P + (0 * BM + row) * XPA + kq) = q1;
+        *reinterpret_cast<bf16x4*>(P + (1 * BM + row) * XPA + kq) = q2;
+        *reinterpret_cast<bf16x4*>(P + (2 * BM + row) * XPA + kq) = q3;
+    };
+    auto write_lds = [&]() {
+        const int kq = (tid & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (tid >> 3) + 32 * j;
+            write_one(Ap, row, kq, ra[j]);
+            write_one(Bp, row, kq, rb[j]);
+        }
+    };
+
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if (nk > 0) load_regs(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        write_lds();
+        __syncthreads();
+        if (kt + 1 < nk) load_regs(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][3], bfr[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * BM + wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                    bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bp + (p * BN + wn * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], lo[i][j], 0, 0, 0);
+                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], hi[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = r0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int c = c0 + wn * 64 + nt * 32 + l31;
+                if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = hi[mt][nt][e] + lo[mt][nt][e];
             }
         }
 }
@@ -586,6 +955,140 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     const long long n = (long long)R * Cn;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n, NT)), block, 0, st, a.slab, nsplit, n, dW);
     CTN_CHECK_LAUNCH("ctn_pw_wgrad/reduce");
+    return CTN_OK;
+}
+
+// ---- split-bf16 entry points ---------------------------------------------------------------------
+int ctn_split_cols(int Cn) { return (Cn + XK - 1) / XK * XK; }
+
+// planes: [3][R][ctn_split_cols(Cn)] bf16, (R, Cn) = transpose ? (cols, rows) : (rows, cols)
+int ctn_split_bf16(const float* W, void* planes, int rows, int cols, int transpose, void* stream) {
+    CTN_REQUIRE(W && planes && rows > 0 && cols > 0, "ctn_split_bf16: bad arguments");
+    CTN_REQUIRE(aligned16(planes), "ctn_split_bf16: planes must be 16-byte aligned");
+    const int R = transpose ? cols : rows, Cn = transpose ? rows : cols, Cnp = ctn_split_cols(Cn);
+    long long nb = ctn_cdivll((long long)R * Cnp, NT);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, W, (__bf16*)planes, rows, cols,
+                       transpose, R, Cn, Cnp);
+    CTN_CHECK_LAUNCH("ctn_split_bf16");
+    return CTN_OK;
+}
+
+}  // extern "C"
+
+template <typename TL>
+static void launch_x6(const X6Args& xa, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const PwArgs& a = xa.p;
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(NT);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, xa);
+    else if (pro) {
+        if (residual) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, xa);
+        else hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, xa);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, xa);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, xa);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, xa);
+    else hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, xa);
+}
+
+static void dispatch_x6(X6Args& xa, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    PwArgs& a = xa.p;
+    const int id = pick_tile(a.M, a.R, a.Kp);
+    int tm, tn;
+    tile_dims(id, &tm, &tn);
+    a.tiles_r = ctn_cdiv(a.R, tm);
+    a.tiles_c = ctn_cdiv(a.Kp, tn);
+    switch (id) {
+        case 0: case 7: launch_x6<T128x128>(xa, pro, residual, stats, relu, gln_bwd, st); break;
+        case 1: case 4: case 6: launch_x6<T128x64>(xa, pro, residual, stats, relu, gln_bwd, st); break;
+        case 2: launch_x6<T64x128>(xa, pro, residual, stats, relu, gln_bwd, st); break;
+        default: launch_x6<T64x64>(xa, pro, residual, stats, relu, gln_bwd, st); break;
+    }
+}
+
+extern "C" {
+
+// same contract as ctn_pw_gemm, with the weights given as pre-split planes [3][R][ctn_split_cols(Cn)] (already
+// oriented rows = output channels: use transpose=1 in ctn_split_bf16 for the input-gradient form).
+int ctn_pw_gemm_x6(const void* Wp, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
+                   const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+                   const float* pro_alpha, float* pro_ms_out,
+                   const float* residual, const float* epi_alpha, double* epi_part, int relu_out, void* stream) {
+    int rc = check_common("ctn_pw_gemm_x6", (const float*)Wp, X, Out, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(!relu_out || !(residual || epi_part || pro_part), "ctn_pw_gemm_x6: relu_out only on the plain GEMM");
+    CTN_REQUIRE(!(residual && epi_part), "ctn_pw_gemm_x6: residual and stats epilogues are exclusive");
+    CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0), "ctn_pw_gemm_x6: incomplete prologue arguments");
+    CTN_REQUIRE(!epi_part || epi_alpha, "ctn_pw_gemm_x6: stats epilogue needs alpha");
+    CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm_x6: residual must be 16-byte aligned");
+    X6Args xa{};
+    PwArgs& a = xa.p;
+    a.X = X; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
+    a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
+    a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
+    xa.Wp = (const __bf16*)Wp; xa.Cnp = ctn_split_cols(Cn);
+    dispatch_x6(xa, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_gemm_x6");
+    return CTN_OK;
+}
+
+int ctn_pw_dgrad_gln_x6(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                        const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                        void* stream) {
+    int rc = check_common("ctn_pw_dgrad_gln_x6", (const float*)Wp, dOut, dN, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(y && gamma && alpha && ms && sums_part && aligned16(y), "ctn_pw_dgrad_gln_x6: bad arguments");
+    X6Args xa{};
+    PwArgs& a = xa.p;
+    a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
+    xa.Wp = (const __bf16*)Wp; xa.Cnp = ctn_split_cols(Cn);
+    dispatch_x6(xa, false, false, false, false, true, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln_x6");
+    return CTN_OK;
+}
+
+static void wgrad_x6_plan(int M, int R, int Cn, int Kp, int* chunk, int* chunks_per_m) {
+    const int tiles = ctn_cdiv(R, BM) * ctn_cdiv(Cn, BN);
+    int cpm = ctn_cdiv(512, tiles * M);
+    const int max_cpm = ctn_cdiv(Kp, 256);
+    if (cpm > max_cpm) cpm = max_cpm;
+    if (cpm < 1) cpm = 1;
+    int c = ctn_cdiv(ctn_cdiv(Kp, cpm), XK) * XK;
+    *chunk = c;
+    *chunks_per_m = ctn_cdiv(Kp, c);
+}
+
+size_t ctn_pw_wgrad_x6_workspace(int M, int R, int Cn, int Kp) {
+    int chunk, cpm;
+    wgrad_x6_plan(M, R, Cn, Kp, &chunk, &cpm);
+    return (size_t)M * cpm * R * Cn * sizeof(float);
+}
+
+int ctn_pw_wgrad_x6(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                    const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("ctn_pw_wgrad_x6", dW, X, (const float*)dOut, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(!pro_ms || (pro_gamma && pro_beta && pro_alpha), "ctn_pw_wgrad_x6: incomplete prologue arguments");
+    WgArgs a{};
+    a.dOut = dOut; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.tiles_r = ctn_cdiv(R, BM); a.tiles_c = ctn_cdiv(Cn, BN);
+    wgrad_x6_plan(M, R, Cn, Kp, &a.chunk, &a.chunks_per_m);
+    const int nsplit = M * a.chunks_per_m;
+    if (workspace == nullptr || workspace_bytes < (size_t)nsplit * R * Cn * sizeof(float)) {
+        ctn_set_error("ctn_pw_wgrad_x6: workspace too small");
+        return CTN_ERR_WORKSPACE;
+    }
+    a.pro_gamma = pro_gamma; a.pro_beta = pro_beta; a.pro_alpha = pro_alpha; a.pro_ms = pro_ms;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(NT);
+    if (pro_ms) hipLaunchKernelGGL((pw_wgrad_x6_kernel<PRO_PRELU_NORM>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_wgrad_x6_kernel<PRO_NONE>), grid, block, 0, st, a);
+    CTN_CHECK_LAUNCH("ctn_pw_wgrad_x6");
+    const long long n = (long long)R * Cn;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n, NT)), block, 0, st, a.slab, nsplit, n, dW);
+    CTN_CHECK_LAUNCH("ctn_pw_wgrad_x6/reduce");
     return CTN_OK;
 }
 

@@ -20,8 +20,34 @@ import torch
 
 from ._lib import lib, CtnError
 
+import os
+
 F32 = torch.float32
 F64 = torch.float64
+BF16 = torch.bfloat16
+
+# GEMM arithmetic: "fp32" = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains); "x6" = split-bf16 emulation on the
+# bf16 matrix cores (three bf16 pieces per operand, six MFMAs, fp32-level accuracy at 2.7x the fp32-MFMA rate).
+_GEMM_MODE = os.environ.get("CTN_GEMM_MODE", "fp32")
+
+
+def set_gemm_mode(mode):
+    global _GEMM_MODE
+    if mode not in ("fp32", "x6"):
+        raise ValueError("gemm mode must be 'fp32' or 'x6'")
+    _GEMM_MODE = mode
+
+
+def gemm_mode():
+    return _GEMM_MODE
+
+
+def _split_planes(W, rows, cols, transpose):
+    """[3][R][Cnp] bf16 planes of a weight matrix (W^T when transpose)."""
+    R, Cn = (cols, rows) if transpose else (rows, cols)
+    planes = torch.empty((3, R, lib.ctn_split_cols(Cn)), dtype=BF16, device=W.device)
+    lib.call("ctn_split_bf16", _p(W), _p(planes), rows, cols, int(transpose), _stream())
+    return planes
 
 
 def _p(t):
@@ -38,7 +64,7 @@ def _chk(*ts):
             continue
         if not t.is_cuda:
             raise CtnError("the HIP path needs tensors on the GPU (got a CPU tensor); there is no CPU fallback")
-        if t.dtype not in (F32, F64, torch.int64, torch.int32):
+        if t.dtype not in (F32, F64, BF16, torch.int64, torch.int32):
             raise CtnError("unsupported dtype %s" % t.dtype)
         if not t.is_contiguous():
             raise CtnError("internal error: non-contiguous tensor reached the C ABI")
@@ -78,10 +104,33 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
         epi_part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=X.device)
     pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
     _chk(W, X, pp, pg, pb, pa, residual, epi_alpha, ms_out)
+    if _GEMM_MODE == "x6":
+        wr, wc = (Cn, R) if trans_w else (R, Cn)                 # W as stored
+        planes = _split_planes(W, wr, wc, trans_w)
+        lib.call("ctn_pw_gemm_x6", _p(planes), _p(X), _p(out), M, R, Cn, K, Kp,
+                 _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
+                 int(relu_out), _stream())
+        return out, epi_part
     lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, int(trans_w),
              _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
              int(relu_out), _stream())
     return out, epi_part
+
+
+def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
+    """dN = W^T . dOut (W stored [Cn, R]) + the gLN-backward sums partials.  Returns (dN, sums_part)."""
+    M, _, Kp = dOut.shape
+    dn = torch.empty((M, R, Kp), dtype=F32, device=dOut.device)
+    part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=dOut.device)
+    _chk(W, dOut, y, gamma, alpha, ms)
+    if _GEMM_MODE == "x6":
+        planes = _split_planes(W, Cn, R, True)
+        lib.call("ctn_pw_dgrad_gln_x6", _p(planes), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha),
+                 _p(ms), _p(part), _stream())
+    else:
+        lib.call("ctn_pw_dgrad_gln", _p(W), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha), _p(ms),
+                 _p(part), _stream())
+    return dn, part
 
 
 _ws_cache = {}
@@ -101,12 +150,13 @@ def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None):
     """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2]).  out: optional destination."""
     M, _, Kp = X.shape
     dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
-    nbytes = lib.ctn_pw_wgrad_workspace(M, R, Cn, Kp)
+    x6 = _GEMM_MODE == "x6"
+    nbytes = (lib.ctn_pw_wgrad_x6_workspace if x6 else lib.ctn_pw_wgrad_workspace)(M, R, Cn, Kp)
     ws = _workspace(nbytes, X.device, "wgrad")
     pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
     _chk(dOut, X, pg, pb, pa, pms)
-    lib.call("ctn_pw_wgrad", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb), _p(pa), _p(pms),
-             _p(ws), nbytes, _stream())
+    lib.call("ctn_pw_wgrad_x6" if x6 else "ctn_pw_wgrad", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb),
+             _p(pa), _p(pms), _p(ws), nbytes, _stream())
     return dW
 
 
@@ -238,11 +288,9 @@ class GlnBlock(torch.autograd.Function):
         dev = x.device
         st = _stream()
         # -- second 1x1: input gradient (+ gLN2 backward sums) and weight gradient
-        np2 = lib.ctn_pw_stats_parts(M, H, Kp)
-        dn2 = torch.empty((M, H, Kp), dtype=F32, device=dev)
-        s2p = torch.empty((M, np2, 2), dtype=F64, device=dev)
         _chk(dout, x, h1, d)
-        lib.call("ctn_pw_dgrad_gln", _p(w2), _p(dout), _p(dn2), M, H, B, K, Kp, _p(d), _p(g2), _p(a2), _p(ms2), _p(s2p), st)
+        dn2, s2p = pw_dgrad_gln(w2, dout, H, B, K, d, g2, a2, ms2)
+        np2 = s2p.shape[1]
         dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2), out=sinks[8] if direct else None)
         # -- gLN2 <- PReLU2 <- depthwise <- gLN1 output, one pass
         Fr = lib.ctn_dw_bwd_rows(P, 1)

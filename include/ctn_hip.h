@@ -73,6 +73,26 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
                  void* workspace, size_t workspace_bytes, void* stream);
 size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
 
+/* ---- split-bf16 ("x6") forms of the same GEMMs ------------------------------------------------
+ * fp32-accurate products on the bf16 matrix cores: every fp32 operand is split exactly into three bf16 pieces and the
+ * six piece-products of weight >= 2^-16 are accumulated in fp32 (dropped terms <= 2^-24 |a.b|).  Same contracts as the
+ * fp32-MFMA entry points above; the weights are passed as pre-split planes made by ctn_split_bf16. */
+int ctn_split_cols(int Cn);                 /* contraction length padded to the kernels' k-tile (32) */
+/* planes: [3][R][ctn_split_cols(Cn)] bf16 with (R, Cn) = transpose ? (cols, rows) : (rows, cols); W is [rows, cols].
+ * transpose = 1 prepares the input-gradient (W^T) form. */
+int ctn_split_bf16(const float* W, void* planes, int rows, int cols, int transpose, void* stream);
+int ctn_pw_gemm_x6(const void* Wp, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
+                   const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+                   const float* pro_alpha, float* pro_ms_out,
+                   const float* residual, const float* epi_alpha, double* epi_part, int relu_out, void* stream);
+int ctn_pw_dgrad_gln_x6(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                        const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                        void* stream);
+int ctn_pw_wgrad_x6(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                    const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t ctn_pw_wgrad_x6_workspace(int M, int R, int Cn, int Kp);
+
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
  * PReLU (:224,:259) and GlobalLayerNorm (:225,:260,:338-361) on either side fused in. */
