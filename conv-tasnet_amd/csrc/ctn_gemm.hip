@@ -68,6 +68,23 @@ struct PwArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Operand prologue: gLN(prelu(x)) = gamma*((prelu(x)-mean)*rstd)+beta, folded to one select + one FMA per element:
+//   gs = gamma*rstd, cc = beta - gs*mean  ->  x' = x * (x >= 0 ? gs : gs*alpha) + cc ;  0 for frames k >= K.
+__device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, float b, float alpha, float mean, float rstd) {
+    const float gs = g * rstd, cc = b - gs * mean, gn = gs * alpha;
+    v.x = fmaf(v.x, v.x >= 0.f ? gs : gn, cc);
+    v.y = fmaf(v.y, v.y >= 0.f ? gs : gn, cc);
+    v.z = fmaf(v.z, v.z >= 0.f ? gs : gn, cc);
+    v.w = fmaf(v.w, v.w >= 0.f ? gs : gn, cc);
+    if (k + 3 >= K) {                       // only the last column tile of an utterance
+        if (k + 0 >= K) v.x = 0.f;
+        if (k + 1 >= K) v.y = 0.f;
+        if (k + 2 >= K) v.z = 0.f;
+        if (k + 3 >= K) v.w = 0.f;
+    }
+    return v;
+}
+
 // ---- shared epilogue (fp32-MFMA and split-bf16 kernels: the 32x32 C/D register map is dtype-independent) ----
 // Each wave transposes its accumulators through a private LDS patch (32 rows at a time) so that global traffic
 // is 16 bytes per lane along frames instead of 64 dword accesses; residual / ReLU / PReLU-statistics / gLN-backward
@@ -186,7 +203,9 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
     // B (activations): X[i][k..k+3]:            k4 = tid % (TN/4), i = tid / (TN/4) (+ (1024/TN) j)
     const int nk = (a.Cn + BK - 1) / BK;
 
-    auto load_tile = [&](int kt, float4 (&ra)[A_L], float4 (&rb)[B_L]) {
+    // PRO: the raw tile and its (gamma, beta) stay in registers across the MFMA phase; the norm is applied when the
+    // tile is written to LDS, so the global loads never have a consumer before the compute they overlap with.
+    auto load_tile = [&](int kt, float4 (&ra)[A_L], float4 (&rb)[B_L], float2 (&rp)[B_L]) {
         const int kc = kt * BK;
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
@@ -204,20 +223,16 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
         for (int j = 0; j < B_L; ++j) {
             const int i = kc + tid / (TN / 4) + (1024 / TN) * j, k = c0 + (tid % (TN / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 gb = make_float2(0.f, 0.f);
             if (i < a.Cn && k < a.Kp) {
                 v = ld4(Xm + (size_t)i * a.Kp + k);
-                if constexpr (PRO == PRO_PRELU_NORM) {
-                    const float g = a.pro_gamma[i], b = a.pro_beta[i];
-                    v.x = (k + 0 < a.K) ? g * ((prelu_f(v.x, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    v.y = (k + 1 < a.K) ? g * ((prelu_f(v.y, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    v.z = (k + 2 < a.K) ? g * ((prelu_f(v.z, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    v.w = (k + 3 < a.K) ? g * ((prelu_f(v.w, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                }
+                if constexpr (PRO == PRO_PRELU_NORM) gb = make_float2(a.pro_gamma[i], a.pro_beta[i]);
             }
             rb[j] = v;
+            rp[j] = gb;
         }
     };
-    auto store_tile = [&](int buf, const float4 (&ra)[A_L], const float4 (&rb)[B_L]) {
+    auto store_tile = [&](int buf, const float4 (&ra)[A_L], const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
         float* const Ab = As + buf * BK * LDA;
         float* const Bb = Bs + buf * BK * LDB;
 #pragma unroll
@@ -236,7 +251,9 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
             const int i = tid / (TN / 4) + (1024 / TN) * j, k = (tid % (TN / 4)) * 4;
-            *reinterpret_cast<float4*>(Bb + i * LDB + k) = rb[j];
+            float4 v = rb[j];
+            if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
+            *reinterpret_cast<float4*>(Bb + i * LDB + k) = v;
         }
     };
 
@@ -272,21 +289,22 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
     // set (written to the other LDS buffer after the MFMAs) and tile kt+2 is in flight into the second set -- the
     // global-load latency is covered by two k-tiles of MFMA work instead of one.
     float4 pa[A_L], pb[B_L], qa[A_L], qb[B_L];
-    load_tile(0, pa, pb);
-    store_tile(0, pa, pb);
-    if (nk > 1) load_tile(1, pa, pb);
-    if (nk > 2) load_tile(2, qa, qb);
+    float2 pp[B_L], qp[B_L];
+    load_tile(0, pa, pb, pp);
+    store_tile(0, pa, pb, pp);
+    if (nk > 1) load_tile(1, pa, pb, pp);
+    if (nk > 2) load_tile(2, qa, qb, qp);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         compute(0);
-        if (kt + 1 < nk) store_tile(1, pa, pb);
+        if (kt + 1 < nk) store_tile(1, pa, pb, pp);
         __syncthreads();
-        if (kt + 3 < nk) load_tile(kt + 3, pa, pb);
+        if (kt + 3 < nk) load_tile(kt + 3, pa, pb, pp);
         if (kt + 1 < nk) {
             compute(1);
-            if (kt + 2 < nk) store_tile(0, qa, qb);
+            if (kt + 2 < nk) store_tile(0, qa, qb, qp);
             __syncthreads();
-            if (kt + 4 < nk) load_tile(kt + 4, qa, qb);
+            if (kt + 4 < nk) load_tile(kt + 4, qa, qb, qp);
         }
     }
 
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
         b_src[j] = Xm + (size_t)b_ch[j] * a.Kp + (b_kok ? b_k : 0);
     }
     const size_t b_step = (size_t)XK * a.Kp;
-    auto load_regs = [&](int kt, uint4 (&ra)[3][A_L], float4 (&rb)[B_L]) {
+    auto load_regs = [&](int kt, uint4 (&ra)[3][A_L], float4 (&rb)[B_L], float2 (&rp)[B_L]) {
         const int kc = kt * XK;
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
@@ -415,21 +433,16 @@ __global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
         for (int j = 0; j < B_L; ++j) {
             const int i = kc + b_ch[j];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 gb = make_float2(0.f, 0.f);
             if (i < a.Cn && b_kok) {
                 v = ld4(b_src[j] + (size_t)kt * b_step);
-                if constexpr (PRO == PRO_PRELU_NORM) {
-                    const int k = b_k;
-                    const float g = a.pro_gamma[i], b = a.pro_beta[i];
-                    v.x = (k + 0 < a.K) ? g * ((prelu_f(v.x, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    v.y = (k + 1 < a.K) ? g * ((prelu_f(v.y, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    v.z = (k + 2 < a.K) ? g * ((prelu_f(v.z, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    v.w = (k + 3 < a.K) ? g * ((prelu_f(v.w, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                }
+                if constexpr (PRO == PRO_PRELU_NORM) gb = make_float2(a.pro_gamma[i], a.pro_beta[i]);
             }
             rb[j] = v;
+            rp[j] = gb;
         }
     };
-    auto write_lds = [&](const uint4 (&ra)[3][A_L], const float4 (&rb)[B_L]) {
+    auto write_lds = [&](const uint4 (&ra)[3][A_L], const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
             const int r = (tid >> 2) + 64 * j, c = (tid & 3) * 8;
@@ -439,8 +452,10 @@ __global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
             const int i = tid / (TN / 4) + (1024 / TN) * j, k = (tid % (TN / 4)) * 4;
+            float4 v = rb[j];
+            if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
             bf16x4 q1, q2, q3;
-            split3x4(rb[j], q1, q2, q3);
+            split3x4(v, q1, q2, q3);
             *reinterpret_cast<bf16x4*>(Bp + (0 * XK + i) * PB + k) = q1;
             *reinterpret_cast<bf16x4*>(Bp + (1 * XK + i) * PB + k) = q2;
             *reinterpret_cast<bf16x4*>(Bp + (2 * XK + i) * PB + k) = q3;
@@ -497,11 +512,12 @@ __global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
     // (register pressure), see profiles/README.md.
     uint4 pa[3][A_L];
     float4 pb[B_L];
-    load_regs(0, pa, pb);
+    float2 pp[B_L];
+    load_regs(0, pa, pb, pp);
     for (int kt = 0; kt < nk; ++kt) {
-        write_lds(pa, pb);
+        write_lds(pa, pb, pp);
         __syncthreads();
-        if (kt + 1 < nk) load_regs(kt + 1, pa, pb);
+        if (kt + 1 < nk) load_regs(kt + 1, pa, pb, pp);
         compute();
         __syncthreads();
     }
@@ -569,6 +585,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     }
 
     float4 ra[2], rb[2];
+    float2 rg[2];
     const int nk = (ke - kb + WK - 1) / WK;
     auto load_tile = [&](int kt) {
         const int k = kb + kt * WK + (tid & 3) * 4;
@@ -582,22 +599,20 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
             const int c = c0 + row;
             if (c < a.Cn && k < ke) {
                 x = ld4(Xm + (size_t)c * a.Kp + k);
-                if constexpr (PRO == PRO_PRELU_NORM) {
-                    const float g = a.pro_gamma[c], b = a.pro_beta[c];
-                    x.x = (k + 0 < a.K) ? g * ((prelu_f(x.x, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    x.y = (k + 1 < a.K) ? g * ((prelu_f(x.y, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    x.z = (k + 2 < a.K) ? g * ((prelu_f(x.z, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    x.w = (k + 3 < a.K) ? g * ((prelu_f(x.w, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                }
+                if constexpr (PRO == PRO_PRELU_NORM) rg[j] = make_float2(a.pro_gamma[c], a.pro_beta[c]);
+            } else if constexpr (PRO == PRO_PRELU_NORM) {
+                rg[j] = make_float2(0.f, 0.f);
             }
             rb[j] = x;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int kt) {
         const int kq = (tid & 3) * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (tid >> 2) + 64 * j;
+            if constexpr (PRO == PRO_PRELU_NORM)      // applied here, after the MFMA phase the loads overlapped with
+                rb[j] = pro_apply(rb[j], kb + kt * WK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
             As[buf][row][kq + 0] = ra[j].x; As[buf][row][kq + 1] = ra[j].y;
             As[buf][row][kq + 2] = ra[j].z; As[buf][row][kq + 3] = ra[j].w;
             Bs[buf][row][kq + 0] = rb[j].x; Bs[buf][row][kq + 1] = rb[j].y;
@@ -616,7 +631,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     if (nk > 0) {
         load_tile(0);
-        store_tile(0);
+        store_tile(0, 0);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
         __syncthreads();
     }
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
@@ -678,6 +693,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
     }
     // staging map: 8 threads per row (32 frames = 8 float4), 32 rows per pass, 4 passes for 128 rows
     float4 ra[4], rb[4];
+    float2 rg[4];
     const int nk = (ke - kb + XK - 1) / XK;
     auto load_regs = [&](int kt) {
         const int k = kb + kt * XK + (tid & 7) * 4;
@@ -691,13 +707,9 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
             const int c = c0 + row;
             if (c < a.Cn && k < ke) {
                 x = ld4(Xm + (size_t)c * a.Kp + k);
-                if constexpr (PRO == PRO_PRELU_NORM) {
-                    const float g = a.pro_gamma[c], b = a.pro_beta[c];
-                    x.x = (k + 0 < a.K) ? g * ((prelu_f(x.x, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    x.y = (k + 1 < a.K) ? g * ((prelu_f(x.y, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    x.z = (k + 2 < a.K) ? g * ((prelu_f(x.z, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                    x.w = (k + 3 < a.K) ? g * ((prelu_f(x.w, p_alpha) - p_mean) * p_rstd) + b : 0.f;
-                }
+                if constexpr (PRO == PRO_PRELU_NORM) rg[j] = make_float2(a.pro_gamma[c], a.pro_beta[c]);
+            } else if constexpr (PRO == PRO_PRELU_NORM) {
+                rg[j] = make_float2(0.f, 0.f);
             }
             rb[j] = x;
         }
@@ -709,12 +721,14 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
         *reinterpret_cast<bf16x4*>(P + (1 * BM + row) * XPA + kq) = q2;
         *reinterpret_cast<bf16x4*>(P + (2 * BM + row) * XPA + kq) = q3;
     };
-    auto write_lds = [&]() {
+    auto write_lds = [&](int kt) {
         const int kq = (tid & 7) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = (tid >> 3) + 32 * j;
             write_one(Ap, row, kq, ra[j]);
+            if constexpr (PRO == PRO_PRELU_NORM)
+                rb[j] = pro_apply(rb[j], kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
             write_one(Bp, row, kq, rb[j]);
         }
     };
@@ -730,7 +744,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     if (nk > 0) load_regs(0);
     for (int kt = 0; kt < nk; ++kt) {
-        write_lds();
+        write_lds(kt);
         __syncthreads();
         if (kt + 1 < nk) load_regs(kt + 1);
 #pragma unroll
