@@ -330,6 +330,10 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int XK = 32;            // channels per k-tile (two 16-deep MFMA steps)
+#ifndef CTN_X6_PF
+#define CTN_X6_PF 2
+#endif
+constexpr int X6_PF = CTN_X6_PF;
 constexpr int XPA = 40;           // A-plane row pitch in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
 
 template <typename TL>
@@ -366,7 +370,8 @@ struct X6Args {
 };
 
 template <typename TL, int PRO, int EPI>
-__global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
+__global__ __launch_bounds__(NT, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192) ? 2 : 1))
+void pw_gemm_x6_kernel(X6Args xa) {
     const PwArgs& a = xa.p;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN;
     constexpr int PB = X6<TL>::PB;
@@ -508,18 +513,39 @@ __global__ __launch_bounds__(NT) void pw_gemm_x6_kernel(X6Args xa) {
     }
     };
 
-    // register prefetch (distance 1), one LDS buffer, two barriers per k-tile.  A distance-2 variant measured slower
-    // (register pressure), see profiles/README.md.
+    // One LDS buffer, two barriers per k-tile; the global loads of the next tile(s) wait in registers.
+    // X6_PF = 2 keeps two staging sets in flight (prefetch distance 2).
     uint4 pa[3][A_L];
     float4 pb[B_L];
     float2 pp[B_L];
     load_regs(0, pa, pb, pp);
-    for (int kt = 0; kt < nk; ++kt) {
-        write_lds(pa, pb, pp);
-        __syncthreads();
-        if (kt + 1 < nk) load_regs(kt + 1, pa, pb, pp);
-        compute();
-        __syncthreads();
+    if constexpr (X6_PF == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            write_lds(pa, pb, pp);
+            __syncthreads();
+            if (kt + 1 < nk) load_regs(kt + 1, pa, pb, pp);
+            compute();
+            __syncthreads();
+        }
+    } else {
+        uint4 qa[3][A_L];
+        float4 qb[B_L];
+        float2 qp[B_L];
+        if (nk > 1) load_regs(1, qa, qb, qp);
+        for (int kt = 0; kt < nk; kt += 2) {
+            write_lds(pa, pb, pp);
+            __syncthreads();
+            if (kt + 2 < nk) load_regs(kt + 2, pa, pb, pp);
+            compute();
+            __syncthreads();
+            if (kt + 1 < nk) {
+                write_lds(qa, qb, qp);
+                __syncthreads();
+                if (kt + 3 < nk) load_regs(kt + 3, qa, qb, qp);
+                compute();
+                __syncthreads();
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
