@@ -586,10 +586,11 @@ struct WgArgs {
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
 };
 
-template <int PRO>
+template <int PRO, int WT>     // WT x WT output tile (128 or 64), waves 2x2
 __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
-    __shared__ float As[2][BM][LDW];
-    __shared__ float Bs[2][BN][LDW];
+    constexpr int HT = WT / 2, MTW = WT / 64, NL = WT / 64;     // wave tile edge, MFMA tiles per wave edge, loads/thread
+    __shared__ float As[2][WT][LDW];
+    __shared__ float Bs[2][WT][LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bid = blockIdx.x;
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     const int m = sp / a.chunks_per_m, ch = sp % a.chunks_per_m;
     const int kb = ch * a.chunk;
     const int ke = min(kb + a.chunk, a.Kp);
-    const int r0 = rt * BM, c0 = ct * BN;
+    const int r0 = rt * WT, c0 = ct * WT;
     const float* __restrict__ Gm = a.dOut + (size_t)m * a.R * a.Kp;
     const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
 
@@ -610,13 +611,13 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         p_alpha = a.pro_alpha[0];
     }
 
-    float4 ra[2], rb[2];
-    float2 rg[2];
+    float4 ra[NL], rb[NL];
+    float2 rg[NL];
     const int nk = (ke - kb + WK - 1) / WK;
     auto load_tile = [&](int kt) {
         const int k = kb + kt * WK + (tid & 3) * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NL; ++j) {
             const int row = (tid >> 2) + 64 * j;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r0 + row < a.R && k < ke) v = ld4(Gm + (size_t)(r0 + row) * a.Kp + k);
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     auto store_tile = [&](int buf, int kt) {
         const int kq = (tid & 3) * 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NL; ++j) {
             const int row = (tid >> 2) + 64 * j;
             if constexpr (PRO == PRO_PRELU_NORM)      // applied here, after the MFMA phase the loads overlapped with
                 rb[j] = pro_apply(rb[j], kb + kt * WK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
@@ -646,11 +647,11 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MTW][MTW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -666,27 +667,30 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int s = 0; s < WK / 2; ++s) {
             const int kk = 2 * s + lhi;
-            const float a0 = As[buf][wm * 64 + l31][kk];
-            const float a1 = As[buf][wm * 64 + 32 + l31][kk];
-            const float b0 = Bs[buf][wn * 64 + l31][kk];
-            const float b1 = Bs[buf][wn * 64 + 32 + l31][kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[MTW], bv[MTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                av[i] = As[buf][wm * HT + 32 * i + l31][kk];
+                bv[i] = Bs[buf][wn * HT + 32 * i + l31][kk];
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < MTW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
         __syncthreads();
     }
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int r = r0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            const int r = r0 + wm * HT + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int c = c0 + wn * 64 + nt * 32 + l31;
+            for (int nt = 0; nt < MTW; ++nt) {
+                const int c = c0 + wn * HT + nt * 32 + l31;
                 if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = acc[mt][nt][e];
             }
         }
@@ -953,20 +957,34 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
 
 extern "C" {
 
-static void wgrad_plan(int M, int R, int Cn, int Kp, int* chunk, int* chunks_per_m) {
-    const int tiles = ctn_cdiv(R, BM) * ctn_cdiv(Cn, BN);
-    int cpm = ctn_cdiv(512, tiles * M);            // aim for ~2 workgroups per CU
-    const int max_cpm = ctn_cdiv(Kp, 256);         // but keep >= 256 frames of contraction per slab
+static int g_wgrad_tile = 0;      // 0: heuristic, 64 or 128: forced (ctn_tune_wgrad)
+static int g_wgrad_blocks = 512;   // target workgroups per launch
+
+static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int* chunks_per_m) {
+    // 64x64 output tiles whenever the matrix has enough of them: 4x fewer split-K slabs than 128x128 for the same
+    // number of workgroups (slab traffic = splits x R x Cn x 4 B, written once and read once by the reduce kernel).
+    int wt = g_wgrad_tile ? g_wgrad_tile : ((R >= 64 && Cn >= 64) ? 64 : 128);
+    const int tiles = ctn_cdiv(R, wt) * ctn_cdiv(Cn, wt);
+    int cpm = ctn_cdiv(g_wgrad_blocks, tiles * M);
+    const int max_cpm = ctn_cdiv(Kp, 256);         // keep >= 256 frames of contraction per slab
     if (cpm > max_cpm) cpm = max_cpm;
     if (cpm < 1) cpm = 1;
     int c = ctn_cdiv(ctn_cdiv(Kp, cpm), WK) * WK;
+    *tile = wt;
     *chunk = c;
     *chunks_per_m = ctn_cdiv(Kp, c);
 }
 
+int ctn_tune_wgrad(int tile, int blocks) {
+    if (!(tile == 0 || tile == 64 || tile == 128) || blocks < 1) return CTN_ERR_ARG;
+    g_wgrad_tile = tile;
+    g_wgrad_blocks = blocks;
+    return CTN_OK;
+}
+
 size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp) {
-    int chunk, cpm;
-    wgrad_plan(M, R, Cn, Kp, &chunk, &cpm);
+    int tile, chunk, cpm;
+    wgrad_plan(M, R, Cn, Kp, &tile, &chunk, &cpm);
     return (size_t)M * cpm * R * Cn * sizeof(float);
 }
 
@@ -979,8 +997,9 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     CTN_REQUIRE(!pro_ms || (pro_gamma && pro_beta && pro_alpha), "ctn_pw_wgrad: incomplete prologue arguments");
     WgArgs a{};
     a.dOut = dOut; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
-    a.tiles_r = ctn_cdiv(R, BM); a.tiles_c = ctn_cdiv(Cn, BN);
-    wgrad_plan(M, R, Cn, Kp, &a.chunk, &a.chunks_per_m);
+    int wt;
+    wgrad_plan(M, R, Cn, Kp, &wt, &a.chunk, &a.chunks_per_m);
+    a.tiles_r = ctn_cdiv(R, wt); a.tiles_c = ctn_cdiv(Cn, wt);
     const int nsplit = M * a.chunks_per_m;
     if (workspace == nullptr || workspace_bytes < (size_t)nsplit * R * Cn * sizeof(float)) {
         ctn_set_error("ctn_pw_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)nsplit * R * Cn * sizeof(float));
@@ -989,8 +1008,13 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     a.pro_gamma = pro_gamma; a.pro_beta = pro_beta; a.pro_alpha = pro_alpha; a.pro_ms = pro_ms;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(NT);
-    if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE>), grid, block, 0, st, a);
+    if (wt == 64) {
+        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 64>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 64>), grid, block, 0, st, a);
+    } else {
+        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 128>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 128>), grid, block, 0, st, a);
+    }
     CTN_CHECK_LAUNCH("ctn_pw_wgrad");
     const long long n = (long long)R * Cn;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n, NT)), block, 0, st, a.slab, nsplit, n, dW);
