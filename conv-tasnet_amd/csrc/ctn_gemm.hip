@@ -68,6 +68,14 @@ struct PwArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  The row tiles that re-read the same
+// activation columns are consecutive tile indices, so give each XCD a contiguous range of tile indices: its private
+// L2 then serves the re-reads instead of the fabric.  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // Operand prologue: gLN(prelu(x)) = gamma*((prelu(x)-mean)*rstd)+beta, folded to one select + one FMA per element:
 //   gs = gamma*rstd, cc = beta - gs*mean  ->  x' = x * (x >= 0 ? gs : gs*alpha) + cc ;  0 for frames k >= K.
 __device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, float b, float alpha, float mean, float rstd) {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / TL::WGN, wn = wave % TL::WGN;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int rt = bid % a.tiles_r; bid /= a.tiles_r;
     const int ct = bid % a.tiles_c;
     const int m = bid / a.tiles_c;
@@ -384,7 +392,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / TL::WGN, wn = wave % TL::WGN;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int rt = bid % a.tiles_r; bid /= a.tiles_r;
     const int ct = bid % a.tiles_c;
     const int m = bid / a.tiles_c;
