@@ -38,6 +38,7 @@ def cpu_baseline(max_seconds=30.0):
     """The oracle (torch CPU restatement of the reference step) on this host's cores: bounded sample."""
     from oracle import ctn_oracle as O
     cfg = O.Config(**PAPER)
+    torch.set_num_threads(min(16, torch.get_num_threads()))     # the 1-GPU box's CPU share
     threads = torch.get_num_threads()
     sd = O.init_params(cfg, seed=0)
     state = {}

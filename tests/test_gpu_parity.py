@@ -353,3 +353,64 @@ def test_paper_config_batch_properties():
         # scaling the mixture scales nothing through gLN'd masks but the encoder: est(a*x) = a*est(x) for a > 0
         e3 = m((2.0 * mix).to(DEV))
         assert rel_err(e3, 2.0 * e1) < 1e-3
+
+
+def _config_parity(cfg, M, T, seed, grad_tol=5e-3):
+    torch.manual_seed(seed)
+    m = ctn.ConvTasNet(cfg.N, cfg.L, cfg.B, cfg.H, cfg.P, cfg.X, cfg.R, cfg.C, norm_type=cfg.norm_type,
+                       causal=cfg.causal, mask_nonlinear=cfg.mask_nonlinear).to(DEV)
+    mix, lens, src = O.synth_batch(10 * seed, M, T, C=cfg.C, sr=16000 if cfg.L == 16 else 8000)
+    lens = lens.clone()
+    lens[-1] = T - 1234                       # ragged batch
+    mix[-1, lens[-1]:] = 0
+    src[-1, :, lens[-1]:] = 0
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    est_ref = O.forward(cfg, sd, mix)
+    loss_ref, max_ref, _, _ = O.cal_loss(src, est_ref, lens)
+    loss_ref.backward()
+    est = m(mix.to(DEV))
+    assert rel_err(est, est_ref) < 1e-4
+    loss, max_snr, _, _ = ctn.cal_loss(src.to(DEV), est, lens.to(DEV))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3
+    assert np.abs(max_snr.detach().cpu().numpy() - max_ref.detach().numpy()).max() < 1e-3
+    loss.backward()
+    # scalar gradients (PReLU slopes) can cancel to ~1e-7 of the model's gradient scale, where fp32 itself (CPU
+    # oracle vs fp64) is off by 1e-1 relative: normalise by at least 1e-3 of the largest gradient in the model
+    gmax = max(float(sd[k].grad.abs().max()) for k in sd)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
+        assert err < grad_tol, (k, err)
+        worst = max(worst, err)
+    return worst
+
+
+def test_causal_cln_paper_shape_parity():
+    """BASELINE configs[3]: causal / cLN variant at the paper's channel counts (2 s utterances, M=2, ragged)."""
+    cfg = O.Config(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2, norm_type="cLN", causal=True)
+    _config_parity(cfg, M=2, T=16000, seed=3)
+
+
+def test_three_speaker_l16_parity():
+    """BASELINE configs[4]: C=3, L=16, 16 kHz (K = 3999 frames here), relu and softmax masks, ragged batch."""
+    for mask in ("relu", "softmax"):
+        cfg = O.Config(N=256, L=16, B=256, H=512, P=3, X=8, R=2, C=3, mask_nonlinear=mask)
+        _config_parity(cfg, M=2, T=32000, seed=5)
+
+
+def test_three_speaker_full_length_properties():
+    """configs[4] at its full size (4 s @ 16 kHz, K = 7999): determinism, zero tail, utterance independence."""
+    torch.manual_seed(0)
+    m = ctn.ConvTasNet(256, 16, 256, 512, 3, 8, 4, 3).to(DEV)
+    mix, lens, src = O.synth_batch(0, 2, 64003, C=3, sr=16000)
+    with torch.no_grad():
+        e1 = m(mix.to(DEV))
+        assert e1.shape == (2, 3, 64003)
+        assert torch.equal(e1, m(mix.to(DEV)))
+        assert float(e1[..., 64000:].abs().max()) == 0.0
+        assert rel_err(e1[1:2], m(mix[1:2].to(DEV))) < 1e-6
+    est = m(mix.to(DEV))
+    loss, max_snr, _, _ = ctn.cal_loss(src.to(DEV), est, lens.to(DEV))
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
