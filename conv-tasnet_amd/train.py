@@ -71,12 +71,22 @@ def main():
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--batches", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=8, help="utterances per GPU per step")
+    ap.add_argument("--data-dir", default=None, help="directory with tr/ and cv/ sub-directories of {mix,s1,s2}.json "
+                    "(the reference's manifest layout); default: synthetic mixtures")
     ap.add_argument("--model-path", default="final.pth.tar")
     ap.add_argument("--save-folder", default="exp/models")
     a = ap.parse_args()
     world, rank, _ = parallel.init_distributed()
-    tr = SyntheticLoader(a.batches, a.batch_size, rank=rank, world=world)
-    cv = SyntheticLoader(1, a.batch_size, first_utt=10 ** 6, rank=rank, world=world)
+    if a.data_dir:
+        import os
+        from .data import AudioDataLoader, AudioDataset
+        tr = AudioDataLoader(AudioDataset(os.path.join(a.data_dir, "tr"), a.batch_size, segment=4.0, rank=rank, world=world),
+                             shuffle=True, num_workers=4)
+        cv = AudioDataLoader(AudioDataset(os.path.join(a.data_dir, "cv"), 1, segment=-1, cv_maxlen=6, rank=rank, world=world),
+                             num_workers=0)
+    else:
+        tr = SyntheticLoader(a.batches, a.batch_size, rank=rank, world=world)
+        cv = SyntheticLoader(1, a.batch_size, first_utt=10 ** 6, rank=rank, world=world)
     train({'tr_loader': tr, 'cv_loader': cv}, a.epochs, a.model_path, save_folder=a.save_folder)
 
 

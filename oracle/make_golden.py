@@ -188,7 +188,57 @@ def init_case():
         save("init_seed11_%s" % nt, **arrs)
 
 
+def synth_wave(path, sr=8000):
+    """Deterministic stand-in for a wav file: the file name encodes (id, speaker tag, n_samples)."""
+    base = os.path.basename(path)[:-4]
+    _, uid, tag, n = base.split("_")
+    rs = np.random.RandomState(1000 * int(uid) + {"mix": 0, "s1": 1, "s2": 2}[tag])
+    return rs.uniform(-1, 1, int(n)).astype(np.float32)
+
+
+def data_case():
+    """Minibatch planning + collation of the reference loaders (src/data.py) on a synthetic manifest.
+    librosa is absent: it is stubbed (like visdom) with a loader that synthesises the waveform from the file name,
+    so only the reference's own planning / segmenting / padding logic runs."""
+    import json
+    import tempfile
+    fake = types.ModuleType("librosa")
+    fake.load = lambda path, sr=None: (synth_wave(path), sr)
+    sys.modules["librosa"] = fake
+    from src.data import AudioDataset, _collate_fn
+    sr, seg_s = 8000, 0.5
+    lens = [21000, 13000, 12000, 9000, 8000, 8000, 7999, 6500, 4000, 4000, 3999, 3000, 12345, 4001, 16000, 2000, 5000]
+    tmp = tempfile.mkdtemp()
+    for tag in ("mix", "s1", "s2"):
+        infos = [["/fake/utt_%d_%s_%d.wav" % (i, tag, n), n] for i, n in enumerate(lens)]
+        with open(os.path.join(tmp, tag + ".json"), "w") as f:
+            json.dump(infos, f)
+    arrs = {"lens": np.array(lens), "sample_rate": sr, "segment": seg_s}
+    for name, kw in (("tr_b3", dict(batch_size=3, segment=seg_s)), ("tr_b5", dict(batch_size=5, segment=seg_s)),
+                     ("cv_b2", dict(batch_size=2, segment=-1, cv_maxlen=2.0)), ("cv_b4", dict(batch_size=4, segment=-1, cv_maxlen=8.0))):
+        ds = AudioDataset(tmp, sample_rate=sr, **kw)
+        plan_ids, plan_off, blens, bsum_mix, bsum_src = [], [0], [], [], []
+        for mb in ds.minibatch:
+            ids = [int(os.path.basename(info[0]).split("_")[1]) for info in mb[0]]
+            plan_ids += ids
+            plan_off.append(len(plan_ids))
+            mix, ln, src = _collate_fn([mb])
+            blens.append(np.pad(ln.numpy(), (0, 8 - len(ln)), constant_values=-1))
+            bsum_mix.append(float(mix.double().sum()))
+            bsum_src.append(float((src.double() * torch.arange(1, src.shape[1] + 1).view(1, -1, 1)).sum()))
+            assert mix.shape[0] == src.shape[0] == len(ln) and src.shape[1] == 2
+        arrs[name + ":ids"] = np.array(plan_ids)
+        arrs[name + ":off"] = np.array(plan_off)
+        arrs[name + ":lens"] = np.array(blens)
+        arrs[name + ":sum_mix"] = np.array(bsum_mix)
+        arrs[name + ":sum_src"] = np.array(bsum_src)
+    save("data_plan", **arrs)
+
+
 if __name__ == "__main__":
+    if "--data-only" in sys.argv:
+        data_case()
+        sys.exit(0)
     tiny = dict(N=64, L=20, B=32, H=64, P=3, X=2, R=2, C=2)
     model_case("model_tiny_gln", T=4005, M=2, lengths=[4005, 3777], seed=1, with_intermediates=True, **tiny)
     model_case("model_tiny_cln_causal", T=3001, M=2, lengths=[3001, 2500], seed=2, norm_type="cLN", causal=True,
@@ -201,3 +251,4 @@ if __name__ == "__main__":
     ola_cases()
     init_case()
     solver_case()
+    data_case()

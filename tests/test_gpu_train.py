@@ -141,3 +141,26 @@ def test_evaluate_sisnri_matches_oracle(capsys):
     assert abs(got - want) < 1e-3
     x = np.random.RandomState(0).randn(1000)
     assert abs(cal_SISNR(x, x) - O.cal_sisnr_np(x, x)) < 1e-9
+
+
+def test_streaming_causal_inference_equals_full_forward():
+    """chunk-by-chunk separation with carried state == one forward over the whole signal."""
+    from conv_tasnet_amd.streaming import StreamingSeparator
+    torch.manual_seed(2)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 4, 2, 2, norm_type="cLN", causal=True).to(DEV).eval()
+    S, T = 10, 10 * 537
+    mix, _, _ = O.synth_batch(3, 2, T)
+    with torch.no_grad():
+        full = m(mix.to(DEV))                                  # [2, 2, T]
+    s = StreamingSeparator(m, batch=2)
+    outs, pos = [], 0
+    for n in (40, 7, 133, 2, 64, 291):                         # ragged chunk sizes, in hops
+        outs.append(s.push(mix[:, pos:pos + n * S]))
+        pos += n * S
+    assert pos == T
+    outs.append(s.flush())
+    got = torch.cat(outs, dim=2)
+    assert got.shape == full.shape
+    assert float((got - full).abs().max()) <= 2e-6 * float(full.abs().max())
+    with pytest.raises(ValueError):
+        StreamingSeparator(ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV))
