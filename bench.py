@@ -137,6 +137,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0          # host time to enqueue the timed steps (diagnostic only)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -160,7 +161,7 @@ def main():
                                    "%d x 4s@8kHz utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam" % PER_GPU_BATCH,
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": T_SAMPLES,
                        "parallelism": "dp%d" % world},
-            "mean_loss": round(mean_loss, 4),
+            "mean_loss": round(mean_loss, 4), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
             "model_tflops": round(value * ftrain / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }

@@ -135,6 +135,39 @@ def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
 
 _ws_cache = {}
 
+# Weight-gradient GEMMs do not feed the backward chain (their results are only read by the optimiser), so in
+# direct-gradient mode they run on a second HIP stream and overlap the latency-bound tails of the chain kernels.
+# FlatAdam.step()/the gradient all-reduce join the stream again (join_side_stream()).
+_side = {}
+_SIDE_ENABLED = os.environ.get("CTN_SIDE_STREAM", "1") != "0"
+_SIDE_FIN = os.environ.get("CTN_SIDE_FIN", "0") != "0"   # finishing reductions on the side stream: measured slower
+
+
+def _side_stream(device):
+    st = _side.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side[device] = st
+    return st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for every weight-gradient kernel issued on the side stream."""
+    for dev, st in _side.items():
+        if device is None or dev == device:
+            torch.cuda.current_stream(dev).wait_stream(st)
+
+
+def _wgrad_async(dOut, X, R, Cn, K, out, pro=None):
+    """pw_wgrad on the side stream, ordered after everything issued so far on the current stream."""
+    dev = X.device
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        pw_wgrad(dOut, X, R, Cn, K, pro=pro, out=out, ws_tag="wgrad_side")
+    for t in (dOut, X) + (tuple(pro) if pro is not None else ()):
+        t.record_stream(side)        # the caching allocator must not hand these out before the side stream is done
+
 
 def _workspace(nbytes, device, tag):
     """Scratch that is fully consumed inside one C call (stream-ordered), so one buffer per tag is enough."""
@@ -146,13 +179,13 @@ def _workspace(nbytes, device, tag):
     return buf
 
 
-def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None):
+def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None, ws_tag="wgrad"):
     """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2]).  out: optional destination."""
     M, _, Kp = X.shape
     dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
     x6 = _GEMM_MODE == "x6"
     nbytes = (lib.ctn_pw_wgrad_x6_workspace if x6 else lib.ctn_pw_wgrad_workspace)(M, R, Cn, Kp)
-    ws = _workspace(nbytes, X.device, "wgrad")
+    ws = _workspace(nbytes, X.device, ws_tag)
     pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
     _chk(dOut, X, pg, pb, pa, pms)
     lib.call("ctn_pw_wgrad_x6" if x6 else "ctn_pw_wgrad", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb),
@@ -291,7 +324,12 @@ class GlnBlock(torch.autograd.Function):
         _chk(dout, x, h1, d)
         dn2, s2p = pw_dgrad_gln(w2, dout, H, B, K, d, g2, a2, ms2)
         np2 = s2p.shape[1]
-        dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2), out=sinks[8] if direct else None)
+        side = direct and _SIDE_ENABLED
+        if side:
+            _wgrad_async(dout, d, B, H, K, sinks[8], pro=(g2, b2, a2, ms2))
+            dW2 = None
+        else:
+            dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2), out=sinks[8] if direct else None)
         # -- gLN2 <- PReLU2 <- depthwise <- gLN1 output, one pass
         Fr = lib.ctn_dw_bwd_rows(P, 1)
         pc = torch.empty((Fr, M, H), dtype=F32, device=dev)
@@ -307,14 +345,30 @@ class GlnBlock(torch.autograd.Function):
             dg2, db2, dg1, db1 = (torch.empty((1, H, 1), dtype=F32, device=dev) for _ in range(4))
             da2 = torch.empty((1,), dtype=F32, device=dev)
             da1 = torch.empty((1,), dtype=F32, device=dev)
-        lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), st)
+        side_fin = side and _SIDE_FIN
+        if side_fin:      # parameter-gradient finishing kernels are off the chain too
+            sst = _side_stream(dev)
+            sst.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(sst):
+                lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), _stream())
+            pc.record_stream(sst)
+        else:
+            lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), st)
         # -- gLN1 + PReLU1 backward, in place on dn1
         da1p = torch.empty((M * H,), dtype=F32, device=dev)
         lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), st)
-        reduce_mid(da1p, 1, M * H, 1, out=da1)
+        if not side_fin:
+            reduce_mid(da1p, 1, M * H, 1, out=da1)
         # -- first 1x1
+        if side:
+            _wgrad_async(dn1, x, H, B, K, sinks[0])
+            if side_fin:
+                with torch.cuda.stream(sst):
+                    reduce_mid(da1p, 1, M * H, 1, out=da1)
+                da1p.record_stream(sst)
         dx, _ = pw_gemm(w1, dn1, B, H, K, trans_w=True, residual=dout)
-        dW1 = pw_wgrad(dn1, x, H, B, K, out=sinks[0] if direct else None)
+        if not side:
+            dW1 = pw_wgrad(dn1, x, H, B, K, out=sinks[0] if direct else None)
         if direct:
             return (dx,) + (None,) * 12
         return (dx, dW1.view(H, B, 1), da1, dg1, db1, dD, da2, dg2, db2, dW2.view(B, H, 1), None, None, None)

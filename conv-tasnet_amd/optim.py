@@ -90,6 +90,8 @@ class FlatAdam(torch.optim.Optimizer):
                     seg.zero_()
                 elif p.grad.data_ptr() != seg.data_ptr():
                     seg.copy_(p.grad.reshape(-1))
+        from . import ops
+        ops.join_side_stream(self.flat_grads.device)      # weight-gradient kernels run on a second stream
         g = self.param_groups[0]
         self._step += 1
         b1, b2 = g["betas"]

@@ -57,6 +57,9 @@ def allreduce_gradients(optimizer_or_params):
         return 1.0
     flat = getattr(optimizer_or_params, "flat_grads", None)
     if flat is not None:
+        if flat.is_cuda:
+            from . import ops
+            ops.join_side_stream(flat.device)              # side-stream weight gradients must have landed
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return 1.0 / w
     grads = [p.grad for p in optimizer_or_params if p.grad is not None]
