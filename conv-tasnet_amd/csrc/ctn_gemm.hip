@@ -17,6 +17,8 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -64,6 +66,10 @@ struct PwArgs {
     const float* epi_alpha; double* epi_part;      // EPI_PRELU_STATS: [M, tiles_r*tiles_c, 2]
     const float* bwd_y; const float* bwd_gamma; const float* bwd_alpha;
     const float* bwd_ms; double* bwd_part;         // EPI_GLN_BWD
+    // split-bf16 pipeline: optional per-(m,row) bias added for k < K, and the result also emitted as three bf16 planes
+    const float* row_bias;                         // [M, R] or NULL
+    void* out_planes; size_t out_plane_stride;     // [3][M,R,Kp] bf16 or NULL; stride between planes in elements
+    int store_f32;                                 // 0: skip the fp32 store (planes only)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -91,6 +97,24 @@ __device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, flo
         if (k + 3 >= K) v.w = 0.f;
     }
     return v;
+}
+
+// exact 3-way bf16 split of an fp32 value: v = a + b + c, 8 significand bits each
+struct Bf3 { __bf16 a, b, c; };
+__device__ __forceinline__ Bf3 split3(float v) {
+    Bf3 r;
+    r.a = (__bf16)v;
+    const float r1 = v - (float)r.a;
+    r.b = (__bf16)r1;
+    r.c = (__bf16)(r1 - (float)r.b);
+    return r;
+}
+// four consecutive fp32 -> the three bf16x4 pieces
+__device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2, bf16x4& q3) {
+    const Bf3 s0 = split3(v.x), s1 = split3(v.y), s2 = split3(v.z), s3 = split3(v.w);
+    q1 = bf16x4{s0.a, s1.a, s2.a, s3.a};
+    q2 = bf16x4{s0.b, s1.b, s2.b, s3.b};
+    q3 = bf16x4{s0.c, s1.c, s2.c, s3.c};
 }
 
 // ---- shared epilogue (fp32-MFMA and split-bf16 kernels: the 32x32 C/D register map is dtype-independent) ----
@@ -156,7 +180,20 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     s1 += (t0 + t1) + (t2 + t3);
                     s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
                 }
-                *reinterpret_cast<float4*>(Om + off) = v;
+                if (a.row_bias != nullptr) {
+                    const float bia = a.row_bias[(size_t)m * a.R + r];
+                    v.x += (k + 0 < a.K) ? bia : 0.f; v.y += (k + 1 < a.K) ? bia : 0.f;
+                    v.z += (k + 2 < a.K) ? bia : 0.f; v.w += (k + 3 < a.K) ? bia : 0.f;
+                }
+                if (a.store_f32) *reinterpret_cast<float4*>(Om + off) = v;
+                if (a.out_planes != nullptr) {
+                    bf16x4 q1, q2, q3;
+                    split3x4(v, q1, q2, q3);
+                    __bf16* P = reinterpret_cast<__bf16*>(a.out_planes) + mbase + off;
+                    *reinterpret_cast<bf16x4*>(P) = q1;
+                    *reinterpret_cast<bf16x4*>(P + a.out_plane_stride) = q2;
+                    *reinterpret_cast<bf16x4*>(P + 2 * a.out_plane_stride) = q3;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -335,8 +372,6 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 // prologue).  A fragments are 16-byte row reads; B fragments (contraction = channels, strided in memory) come
 // out of ds_read_b64_tr_b16, the hardware transpose read, from channel-major LDS planes.
 // ===========================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int XK = 32;            // channels per k-tile (two 16-deep MFMA steps)
 #ifndef CTN_X6_PF
 #define CTN_X6_PF 2
@@ -353,23 +388,6 @@ struct X6 {
     static constexpr int STAGE_BYTES = TL::STAGE_FLOATS * 4;
     static constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
 };
-
-struct Bf3 { __bf16 a, b, c; };
-__device__ __forceinline__ Bf3 split3(float v) {
-    Bf3 r;
-    r.a = (__bf16)v;
-    const float r1 = v - (float)r.a;
-    r.b = (__bf16)r1;
-    r.c = (__bf16)(r1 - (float)r.b);
-    return r;
-}
-// four consecutive fp32 -> the three bf16x4 pieces
-__device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2, bf16x4& q3) {
-    const Bf3 s0 = split3(v.x), s1 = split3(v.y), s2 = split3(v.z), s3 = split3(v.w);
-    q1 = bf16x4{s0.a, s1.a, s2.a, s3.a};
-    q2 = bf16x4{s0.b, s1.b, s2.b, s3.b};
-    q3 = bf16x4{s0.c, s1.c, s2.c, s3.c};
-}
 
 struct X6Args {
     PwArgs p;              // W unused
@@ -562,6 +580,169 @@ void pw_gemm_x6_kernel(X6Args xa) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) hi[i][j][e] += lo[i][j][e];
     gemm_epilogue<TL, EPI>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+}
+
+// -------------------------------------------------------------------------------------------
+// "p6": the split-bf16 GEMM with BOTH operands already split in HBM (weights by ctn_split_bf16, activations by the
+// epilogue / elementwise kernel that produced them).  The main loop is then 16-byte copies global -> LDS plus
+// fragment reads and six MFMAs per 16-deep step: no conversion VALU work between the MFMAs.
+// -------------------------------------------------------------------------------------------
+struct P6Args {
+    PwArgs p;                 // X / W unused
+    const __bf16* Wp;         // [3][R][Cnp]  (+ m * w_m_stride when the weights are per utterance)
+    size_t w_plane_stride;    // elements between weight planes
+    size_t w_m_stride;        // 0 or elements between utterances' weight sets
+    const __bf16* Xp;         // [3][M, Cn, Kp]
+    size_t x_plane_stride;
+    int Cnp;
+};
+
+template <typename TL, int EPI>
+__global__ __launch_bounds__(NT, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192) ? 2 : 1))
+void pw_gemm_p6_kernel(P6Args xa) {
+    const PwArgs& a = xa.p;
+    constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN;
+    constexpr int PB = X6<TL>::PB;
+    constexpr int A_L = TM / 64;                  // 16-byte loads per thread per plane (4 threads per row of 32 k)
+    constexpr int B_L = TN / 64;                  // 16-byte loads per thread per plane (TN/8 threads per channel row)
+    constexpr int BT = TN / 8;                    // threads per channel row
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[X6<TL>::SMEM_BYTES];
+    __shared__ double red[NT / 64];
+    __bf16* const Ap = reinterpret_cast<__bf16*>(smem_raw);                  // [3][TM][XPA]
+    __bf16* const Bp = Ap + X6<TL>::A_ELEMS;                                 // [3][XK][PB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WGN, wn = wave % TL::WGN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c;
+    const int m = bid / a.tiles_c;
+    const int r0 = rt * TM, c0 = ct * TN;
+    const int nk = xa.Cnp / XK;
+
+    const __bf16* a_src[A_L];
+    bool a_ok[A_L];
+#pragma unroll
+    for (int j = 0; j < A_L; ++j) {
+        const int r = r0 + (tid >> 2) + 64 * j;
+        a_ok[j] = r < a.R;
+        a_src[j] = xa.Wp + (size_t)m * xa.w_m_stride + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (tid & 3) * 8;
+    }
+    const int b_k = c0 + (tid % BT) * 8;
+    const bool b_kok = b_k < a.Kp;
+    int b_ch[B_L];
+    const __bf16* b_src[B_L];
+#pragma unroll
+    for (int j = 0; j < B_L; ++j) {
+        b_ch[j] = tid / BT + (NT / BT) * j;
+        b_src[j] = xa.Xp + ((size_t)m * a.Cn + b_ch[j]) * a.Kp + (b_kok ? b_k : 0);
+    }
+    const size_t b_step = (size_t)XK * a.Kp;
+
+    uint4 ra[3][A_L], rb[3][B_L];
+    auto load_regs = [&](int kt) {
+        const int kc = kt * XK;
+#pragma unroll
+        for (int j = 0; j < A_L; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (a_ok[j]) v = *reinterpret_cast<const uint4*>(a_src[j] + p * xa.w_plane_stride + kc);
+                ra[p][j] = v;
+            }
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            const bool ok = b_kok && (kc + b_ch[j] < a.Cn);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4*>(b_src[j] + p * xa.x_plane_stride + (size_t)kt * b_step);
+                rb[p][j] = v;
+            }
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_L; ++j) {
+            const int r = (tid >> 2) + 64 * j, c = (tid & 3) * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = ra[p][j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            const int i = tid / BT + (NT / BT) * j, k = (tid % BT) * 8;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(Bp + (p * XK + i) * PB + k) = rb[p][j];
+        }
+    };
+
+    f32x16 hi[MT][NTL], lo[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tr_q = (lane >> 2) & 3, tr_f = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    typedef bf16x4 __attribute__((address_space(3))) * lds_b4;
+
+    load_regs(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        write_lds();
+        __syncthreads();
+        if (kt + 1 < nk) load_regs(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MT][3], bfr[NTL][3];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * TM + wm * WM + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const __bf16* base = Bp + (p * XK + ks * 16 + lhi * 8 + tr_q) * PB + wn * WN + j * 32 + tr_f;
+                    const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base));
+                    const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base + 4 * PB));
+                    bfr[j][p] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], lo[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], lo[i][j], 0, 0, 0);
+                    hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], hi[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hi[i][j][e] += lo[i][j][e];
+    gemm_epilogue<TL, EPI>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+}
+
+// X [n] fp32 -> planes [3][n] bf16 (n multiple of 4); stand-alone form of what the producers' epilogues emit
+__global__ __launch_bounds__(NT) void split_act_kernel(const float* __restrict__ X, __bf16* __restrict__ P, long long n) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long long)gridDim.x * NT) {
+        bf16x4 q1, q2, q3;
+        split3x4(ld4(X + 4 * i), q1, q2, q3);
+        *reinterpret_cast<bf16x4*>(P + 4 * i) = q1;
+        *reinterpret_cast<bf16x4*>(P + n + 4 * i) = q2;
+        *reinterpret_cast<bf16x4*>(P + 2 * n + 4 * i) = q3;
+    }
 }
 
 // W [rows, cols] fp32 -> planes [3][R][Cnp] bf16 with R x Cn = (transpose ? cols x rows : rows x cols); zero pad to Cnp
@@ -934,6 +1115,7 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     CTN_REQUIRE(!(trans_w && (pro_part || epi_part)), "ctn_pw_gemm: fused prologue/stats only with trans_w=0");
     CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm: residual must be 16-byte aligned");
     PwArgs a{};
+    a.store_f32 = 1;
     a.W = W; a.X = X; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
@@ -954,6 +1136,7 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
     CTN_REQUIRE(y && gamma && alpha && ms && sums_part, "ctn_pw_dgrad_gln: null pointer");
     CTN_REQUIRE(aligned16(y), "ctn_pw_dgrad_gln: y must be 16-byte aligned");
     PwArgs a{};
+    a.store_f32 = 1;
     a.W = W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
     launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
@@ -1094,6 +1277,7 @@ int ctn_pw_gemm_x6(const void* Wp, const float* X, float* Out, int M, int R, int
     CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm_x6: residual must be 16-byte aligned");
     X6Args xa{};
     PwArgs& a = xa.p;
+    a.store_f32 = 1;
     a.X = X; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
@@ -1112,6 +1296,7 @@ int ctn_pw_dgrad_gln_x6(const void* Wp, const float* dOut, float* dN, int M, int
     CTN_REQUIRE(y && gamma && alpha && ms && sums_part && aligned16(y), "ctn_pw_dgrad_gln_x6: bad arguments");
     X6Args xa{};
     PwArgs& a = xa.p;
+    a.store_f32 = 1;
     a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
     xa.Wp = (const __bf16*)Wp; xa.Cnp = ctn_split_cols(Cn);
@@ -1161,6 +1346,73 @@ int ctn_pw_wgrad_x6(const float* dOut, const float* X, float* dW, int M, int R, 
     const long long n = (long long)R * Cn;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n, NT)), block, 0, st, a.slab, nsplit, n, dW);
     CTN_CHECK_LAUNCH("ctn_pw_wgrad_x6/reduce");
+    return CTN_OK;
+}
+
+// ---- p6: both operands pre-split --------------------------------------------------------------------
+// X planes of a whole activation tensor: planes [3][n] bf16
+int ctn_split_act(const float* X, void* planes, long long n, void* stream) {
+    CTN_REQUIRE(X && planes && n > 0 && n % 4 == 0, "ctn_split_act: bad arguments");
+    CTN_REQUIRE(aligned16(X) && aligned16(planes), "ctn_split_act: alignment");
+    long long nb = ctn_cdivll(n / 4, NT);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(split_act_kernel, dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, X, (__bf16*)planes, n);
+    CTN_CHECK_LAUNCH("ctn_split_act");
+    return CTN_OK;
+}
+
+}  // extern "C"
+
+template <typename TL>
+static void launch_p6(const P6Args& xa, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const PwArgs& a = xa.p;
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(NT);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_p6_kernel<TL, EPI_GLN_BWD>), grid, block, 0, st, xa);
+    else if (stats) hipLaunchKernelGGL((pw_gemm_p6_kernel<TL, EPI_PRELU_STATS>), grid, block, 0, st, xa);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_p6_kernel<TL, EPI_RESIDUAL>), grid, block, 0, st, xa);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_p6_kernel<TL, EPI_RELU>), grid, block, 0, st, xa);
+    else hipLaunchKernelGGL((pw_gemm_p6_kernel<TL, EPI_NONE>), grid, block, 0, st, xa);
+}
+
+extern "C" {
+
+// Out[m] = Wp(m) . Xp[m] (+ row_bias[m] for k < K) (+ residual[m]); result stored as fp32 (Out != NULL) and / or as
+// three bf16 planes (out_planes != NULL).  Wp: [3][R][ctn_split_cols(Cn)] bf16, per utterance when w_per_m != 0
+// (then [M][3][R][Cnp]).  Xp: [3][M,Cn,Kp] bf16.  y/gamma/alpha/ms/sums_part non-NULL selects the gLN-backward epilogue.
+int ctn_pw_gemm_p6(const void* Wp, int w_per_m, const void* Xp, float* Out, void* out_planes, int M, int R, int Cn,
+                   int K, int Kp, const float* row_bias, const float* residual, const float* epi_alpha, double* epi_part,
+                   int relu_out, const float* bwd_y, const float* bwd_gamma, const float* bwd_alpha, const float* bwd_ms,
+                   double* bwd_part, void* stream) {
+    CTN_REQUIRE(Wp && Xp && (Out || out_planes), "ctn_pw_gemm_p6: null pointer");
+    CTN_REQUIRE(M > 0 && R > 0 && Cn > 0 && K > 0 && Kp >= K && Kp % 8 == 0 && R % 4 == 0, "ctn_pw_gemm_p6: bad sizes");
+    CTN_REQUIRE(aligned16(Wp) && aligned16(Xp) && aligned16(Out) && aligned16(out_planes) && aligned16(residual),
+                "ctn_pw_gemm_p6: alignment");
+    const bool gln = bwd_part != nullptr;
+    CTN_REQUIRE(!gln || (bwd_y && bwd_gamma && bwd_alpha && bwd_ms), "ctn_pw_gemm_p6: incomplete gLN-backward arguments");
+    CTN_REQUIRE((int)(residual != nullptr) + (int)(epi_part != nullptr) + (int)(relu_out != 0) + (int)gln <= 1,
+                "ctn_pw_gemm_p6: at most one of residual / stats / relu / gln-backward epilogues");
+    P6Args xa{};
+    PwArgs& a = xa.p;
+    a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
+    a.bwd_y = bwd_y; a.bwd_gamma = bwd_gamma; a.bwd_alpha = bwd_alpha; a.bwd_ms = bwd_ms; a.bwd_part = bwd_part;
+    a.row_bias = row_bias; a.out_planes = out_planes; a.out_plane_stride = (size_t)M * R * Kp; a.store_f32 = Out != nullptr;
+    xa.Cnp = ctn_split_cols(Cn);
+    xa.Wp = (const __bf16*)Wp; xa.w_plane_stride = (size_t)R * xa.Cnp; xa.w_m_stride = w_per_m ? 3 * xa.w_plane_stride : 0;
+    xa.Xp = (const __bf16*)Xp; xa.x_plane_stride = (size_t)M * Cn * Kp;
+    const int id = pick_tile(M, R, Kp);
+    int tm, tn;
+    tile_dims(id, &tm, &tn);
+    a.tiles_r = ctn_cdiv(R, tm);
+    a.tiles_c = ctn_cdiv(Kp, tn);
+    hipStream_t st = (hipStream_t)stream;
+    switch (id) {
+        case 0: case 7: launch_p6<T128x128>(xa, residual != nullptr, epi_part != nullptr, relu_out != 0, gln, st); break;
+        case 1: case 4: case 6: launch_p6<T128x64>(xa, residual != nullptr, epi_part != nullptr, relu_out != 0, gln, st); break;
+        case 2: launch_p6<T64x128>(xa, residual != nullptr, epi_part != nullptr, relu_out != 0, gln, st); break;
+        default: launch_p6<T64x64>(xa, residual != nullptr, epi_part != nullptr, relu_out != 0, gln, st); break;
+    }
+    CTN_CHECK_LAUNCH("ctn_pw_gemm_p6");
     return CTN_OK;
 }
 

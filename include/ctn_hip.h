@@ -95,6 +95,15 @@ int ctn_pw_wgrad_x6(const float* dOut, const float* X, float* dW, int M, int R, 
                     const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
                     void* workspace, size_t workspace_bytes, void* stream);
 size_t ctn_pw_wgrad_x6_workspace(int M, int R, int Cn, int Kp);
+/* "p6": both operands already split in HBM.  ctn_split_act is the stand-alone form of what the producers' epilogues
+ * emit (planes [3][n] bf16).  ctn_pw_gemm_p6: Out[m] = Wp(m) . Xp[m] (+ row_bias[m,r] for k < K) (+ residual), stored
+ * as fp32 (Out) and / or as bf16 planes (out_planes [3][M,R,Kp]); Wp [3][R][Cnp], per utterance ([M][3][R][Cnp]) when
+ * w_per_m != 0; one of the residual / PReLU-statistics / ReLU / gLN-backward epilogues as in the fp32 entry points. */
+int ctn_split_act(const float* X, void* planes, long long n, void* stream);
+int ctn_pw_gemm_p6(const void* Wp, int w_per_m, const void* Xp, float* Out, void* out_planes, int M, int R, int Cn,
+                   int K, int Kp, const float* row_bias, const float* residual, const float* epi_alpha, double* epi_part,
+                   int relu_out, const float* bwd_y, const float* bwd_gamma, const float* bwd_alpha, const float* bwd_ms,
+                   double* bwd_part, void* stream);
 
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
