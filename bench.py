@@ -103,7 +103,7 @@ def main():
     import conv_tasnet_amd as ctn
     from conv_tasnet_amd import parallel
     from conv_tasnet_amd.optim import FlatAdam
-    from oracle import ctn_oracle as O   # synthetic inputs only (SURVEY 8d workload definition)
+    from conv_tasnet_amd.train import SyntheticLoader   # synthetic workload of SURVEY 8d (product code, not the oracle)
 
     world, rank, device = parallel.init_distributed()
     if world != args.gpus:
@@ -115,7 +115,8 @@ def main():
     model = ctn.ConvTasNet(**PAPER, norm_type="gLN", causal=False, mask_nonlinear="relu").to(device)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     parallel.broadcast_parameters(opt.flat_params)
-    mix, lens, src = O.synth_batch(rank * PER_GPU_BATCH, PER_GPU_BATCH, T_SAMPLES)   # this rank's shard
+    # this rank's shard: utterances [rank*8, rank*8+8) of the deterministic harmonic-mixture workload
+    mix, lens, src = next(iter(SyntheticLoader(1, PER_GPU_BATCH, samples=T_SAMPLES, rank=rank, world=world)))
     mix, lens, src = mix.to(device), lens.to(device), src.to(device)
     loss_acc = torch.zeros((), device=device)
 

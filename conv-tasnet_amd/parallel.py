@@ -21,12 +21,16 @@ def init_distributed(backend=None):
     world, rank, local = env_world()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        # one GPU per rank; ranks beyond the visible devices wrap around (only useful to rehearse the multi-rank
+        # code path on a single-GPU box together with CTN_DIST_BACKEND=gloo -- RCCL needs distinct devices)
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("CTN_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return world, rank, device
 
 
