@@ -98,7 +98,7 @@ class _EncoderOnly(torch.autograd.Function):
         N, _, L = U.shape
         K = (T - L) // (L // 2) + 1
         Kp = ops.padded_frames(K)
-        mix = mix.contiguous()
+        mix = mix.to(torch.float32).contiguous()
         xcol = torch.empty((M, L, Kp), dtype=torch.float32, device=mix.device)
         ops._chk(mix, U)
         ops.lib.call("ctn_im2col", mix.data_ptr(), xcol.data_ptr(), M, T, L, L, K, Kp, ops._stream())

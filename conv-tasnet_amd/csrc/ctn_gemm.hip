@@ -229,7 +229,6 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
     const int m = bid / a.tiles_c;
     const int r0 = rt * TM, c0 = ct * TN;
     const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
-    float* __restrict__ Om = a.Out + (size_t)m * a.R * a.Kp;
 
     float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
     if constexpr (PRO == PRO_PRELU_NORM) {
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(NT) void split_act_kernel(const float* __restrict__
 }
 
 // W [rows, cols] fp32 -> planes [3][R][Cnp] bf16 with R x Cn = (transpose ? cols x rows : rows x cols); zero pad to Cnp
-__global__ __launch_bounds__(NT) void split_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ P, int rows,
+__global__ __launch_bounds__(NT) void split_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ P,
                                                         int cols, int transpose, int R, int Cn, int Cnp) {
     const long long n = (long long)R * Cnp;
     for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
@@ -1223,7 +1222,7 @@ int ctn_split_bf16(const float* W, void* planes, int rows, int cols, int transpo
     const int R = transpose ? cols : rows, Cn = transpose ? rows : cols, Cnp = ctn_split_cols(Cn);
     long long nb = ctn_cdivll((long long)R * Cnp, NT);
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, W, (__bf16*)planes, rows, cols,
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)nb), dim3(NT), 0, (hipStream_t)stream, W, (__bf16*)planes, cols,
                        transpose, R, Cn, Cnp);
     CTN_CHECK_LAUNCH("ctn_split_bf16");
     return CTN_OK;

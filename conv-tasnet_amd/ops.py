@@ -253,7 +253,9 @@ class Frontend(torch.autograd.Function):
         S = L // 2
         K = (T - L) // S + 1
         Kp = padded_frames(K)
-        mix = _c(mix)
+        if K < 1:
+            raise ValueError("mixture of %d samples is shorter than one encoder frame (L=%d)" % (T, L))
+        mix = _c(mix.to(F32))
         xcol = torch.empty((M, L, Kp), dtype=F32, device=mix.device)
         _chk(mix, U, g0, b0, Wb)
         lib.call("ctn_im2col", _p(mix), _p(xcol), M, T, L, L, K, Kp, _stream())

@@ -164,3 +164,17 @@ def test_streaming_causal_inference_equals_full_forward():
     assert float((got - full).abs().max()) <= 2e-6 * float(full.abs().max())
     with pytest.raises(ValueError):
         StreamingSeparator(ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV))
+
+
+def test_input_dtype_and_layout_are_normalised():
+    torch.manual_seed(0)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV).eval()
+    mix, _, _ = O.synth_batch(0, 2, 1500)
+    with torch.no_grad():
+        ref = m(mix.to(DEV))
+        assert torch.equal(m(mix.double().to(DEV)), ref)                      # float64 input is cast, not reinterpreted
+        wide = torch.zeros(2, 3000)
+        wide[:, ::2] = mix
+        assert torch.equal(m(wide.to(DEV)[:, ::2]), ref)                      # strided view
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 10, device=DEV))
