@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", choices=["fp32", "x6"], default=None,
+                    help="1x1-conv arithmetic: fp32 MFMA (default, bit-exact fp32 chains) or split-bf16 emulation (experimental)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -105,6 +107,9 @@ def main():
     from conv_tasnet_amd.optim import FlatAdam
     from conv_tasnet_amd.train import SyntheticLoader   # synthetic workload of SURVEY 8d (product code, not the oracle)
 
+    if args.gemm:
+        from conv_tasnet_amd import ops as _ops
+        _ops.set_gemm_mode(args.gemm)
     world, rank, device = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
@@ -162,6 +167,7 @@ def main():
                                    "%d x 4s@8kHz utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam" % PER_GPU_BATCH,
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": T_SAMPLES,
                        "parallelism": "dp%d" % world},
+            "gemm_mode": __import__("conv_tasnet_amd").ops.gemm_mode(),
             "mean_loss": round(mean_loss, 4), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
             "model_tflops": round(value * ftrain / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
