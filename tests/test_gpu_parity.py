@@ -443,3 +443,48 @@ def test_split_bf16_presplit_gemm_p6():
     assert rel_err(out, ref) < 1e-6
     assert torch.equal((outp[0].float() + outp[1].float()) + outp[2].float(), out)
     assert float(out[..., K:].abs().max()) == 0.0
+
+
+RANDOM_CASES = [
+    # N,  L,  B,  H, P, X, R, C, norm,  causal, mask,      M, T
+    (16, 8, 8, 16, 3, 1, 1, 1, "gLN", False, "relu", 1, 403),
+    (32, 40, 16, 40, 5, 2, 2, 2, "gLN", False, "relu", 3, 2611),
+    (48, 16, 24, 32, 3, 3, 1, 3, "cLN", True, "softmax", 2, 1999),
+    (16, 20, 8, 16, 2, 3, 2, 2, "cLN", True, "relu", 2, 1500),
+    (32, 20, 16, 32, 5, 3, 1, 2, "gLN", True, "softmax", 2, 1203),
+    (64, 12, 32, 64, 3, 4, 1, 2, "cLN", False, "relu", 1, 777),
+    (16, 20, 8, 16, 3, 2, 1, 4, "gLN", False, "softmax", 2, 660),
+    (32, 20, 16, 32, 3, 1, 3, 2, "gLN", False, "relu", 5, 20 + 10 * 63),      # K = 64 = Kp exactly
+    (32, 20, 16, 32, 3, 2, 1, 2, "gLN", False, "relu", 2, 29),                # a single frame
+]
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES, ids=lambda c: "N%dL%dB%dH%dP%dX%dR%dC%d-%s-%s-%s" % (c[:8] + (c[8], "causal" if c[9] else "nc", c[10])))
+def test_assorted_configs_vs_oracle(case):
+    """Shapes the BASELINE configs do not touch: other kernel sizes, one speaker / four speakers, K == Kp, one frame,
+    odd channel multiples, ragged batches -- forward, loss and every gradient against the CPU oracle."""
+    N, L, B, H, P, X, R, C, norm, causal, mask, M, T = case
+    cfg = O.Config(N=N, L=L, B=B, H=H, P=P, X=X, R=R, C=C, norm_type=norm, causal=causal, mask_nonlinear=mask)
+    torch.manual_seed(sum(case[:8]))
+    m = ctn.ConvTasNet(N, L, B, H, P, X, R, C, norm_type=norm, causal=causal, mask_nonlinear=mask).to(DEV)
+    mix, lens, src = O.synth_batch(77, M, T, C=C)
+    if M > 1 and T > 200:
+        lens = lens.clone()
+        lens[0] = T - 101
+        mix[0, lens[0]:] = 0
+        src[0, :, lens[0]:] = 0
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    est_ref = O.forward(cfg, sd, mix)
+    loss_ref, max_ref, _, _ = O.cal_loss(src, est_ref, lens)
+    loss_ref.backward()
+    est = m(mix.to(DEV))
+    assert est.shape == (M, C, T)
+    assert rel_err(est, est_ref) < 5e-5
+    loss, max_snr, _, _ = ctn.cal_loss(src.to(DEV), est, lens.to(DEV))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3
+    loss.backward()
+    gmax = max(float(sd[k].grad.abs().max()) for k in sd)
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
+        assert err < 5e-3, (k, err)
