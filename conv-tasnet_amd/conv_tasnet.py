@@ -355,8 +355,18 @@ class ChannelwiseLayerNorm(_NormParams):
 
 
 class GlobalLayerNorm(_NormParams):
-    """gLN, src/conv_tasnet.py:338-361.  Stand-alone use runs it as a degenerate fused block is not
-    possible, so it is expressed through the cLN-free primitive path: not on the hot path."""
+    """gLN, src/conv_tasnet.py:338-361.  Inside a TemporalBlock it is fused into the neighbouring kernels; called on
+    its own (inference only) it runs as two passes of the depthwise kernel with a unit tap: statistics, then apply."""
 
     def forward(self, y):
-        raise NotImplementedError("GlobalLayerNorm is fused into the TemporalBlock kernels; call the block")
+        if torch.is_grad_enabled() and (y.requires_grad or self.gamma.requires_grad):
+            raise NotImplementedError("stand-alone GlobalLayerNorm has no backward: use it inside a TemporalBlock "
+                                      "(fused) or under torch.no_grad()")
+        K = y.size(-1)
+        yp = _pad_frames(y.to(torch.float32), K)
+        ch = yp.shape[1]
+        one_tap = torch.ones((ch, 1, 1), dtype=torch.float32, device=yp.device)
+        one = torch.ones((1,), dtype=torch.float32, device=yp.device)          # PReLU slope 1 = identity
+        _, stats = ops.dw_fwd(yp, one_tap, K, 1, False, epi_alpha=one)
+        out, _ = ops.dw_fwd(yp, one_tap, K, 1, False, pro=(stats, self.gamma, self.beta, one))
+        return out[..., :K]

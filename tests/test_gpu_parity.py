@@ -488,3 +488,16 @@ def test_assorted_configs_vs_oracle(case):
         ref = sd[k].grad
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
         assert err < 5e-3, (k, err)
+
+
+def test_standalone_global_layer_norm():
+    gn = ctn.conv_tasnet.GlobalLayerNorm(24).to(DEV)
+    with torch.no_grad():
+        gn.gamma.copy_(torch.randn(1, 24, 1, generator=g(1)))
+        gn.beta.copy_(torch.randn(1, 24, 1, generator=g(2)))
+        y = torch.randn(3, 24, 333, generator=g(3)) * 2 + 0.5
+        out = gn(y.to(DEV))
+    ref = O.gln(y.double(), gn.gamma.detach().cpu().double(), gn.beta.detach().cpu().double())
+    assert rel_err(out, ref) < 2e-6
+    with pytest.raises(NotImplementedError):
+        gn(y.to(DEV).requires_grad_(True))
