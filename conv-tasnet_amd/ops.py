@@ -15,12 +15,11 @@ autograd node:
   SiSnrPit : PIT SI-SNR loss                                      (src/pit_criterion.py:12-77)
 """
 import itertools
+import os
 
 import torch
 
 from ._lib import lib, CtnError
-
-import os
 
 F32 = torch.float32
 F64 = torch.float64
@@ -58,16 +57,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _chk(*ts):
+def _chk(*ts, dtypes=(F32,)):
+    """Every tensor handed to the C ABI: on the GPU, contiguous, fp32 (the kernels reinterpret nothing)."""
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise CtnError("the HIP path needs tensors on the GPU (got a CPU tensor); there is no CPU fallback")
-        if t.dtype not in (F32, F64, BF16, torch.int64, torch.int32):
-            raise CtnError("unsupported dtype %s" % t.dtype)
+        if t.dtype not in dtypes:
+            raise CtnError("the HIP path computes in fp32: got a %s tensor (call .float() on the model / inputs)" % t.dtype)
         if not t.is_contiguous():
             raise CtnError("internal error: non-contiguous tensor reached the C ABI")
+
+
+def _chk_aux(*ts):
+    """fp64 statistics partials, bf16 planes, integer index tensors."""
+    _chk(*ts, dtypes=(F64, BF16, torch.int64, torch.int32))
 
 
 def padded_frames(K):
@@ -103,7 +108,8 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
     if epi_alpha is not None:
         epi_part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=X.device)
     pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
-    _chk(W, X, pp, pg, pb, pa, residual, epi_alpha, ms_out)
+    _chk(W, X, pg, pb, pa, residual, epi_alpha, ms_out)
+    _chk_aux(pp)
     if _GEMM_MODE == "x6":
         wr, wc = (Cn, R) if trans_w else (R, Cn)                 # W as stored
         planes = _split_planes(W, wr, wc, trans_w)
@@ -233,7 +239,8 @@ def dw_fwd(Y, D, K, dilation, causal, pro=None, epi_alpha=None, ms_out=None):
     Z = torch.empty_like(Y)
     epi_part = None if epi_alpha is None else torch.empty((M, H, 2), dtype=F64, device=Y.device)
     pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
-    _chk(Y, D, pp, pg, pb, pa, epi_alpha, ms_out)
+    _chk(Y, D, pg, pb, pa, epi_alpha, ms_out)
+    _chk_aux(pp)
     lib.call("ctn_dw_fwd", _p(Y), _p(Z), _p(D), M, H, K, Kp, P, dilation, int(causal),
              _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(epi_alpha), _p(epi_part), _stream())
     return Z, epi_part
@@ -520,7 +527,8 @@ class SiSnrPit(torch.autograd.Function):
         jsel = torch.empty((Bn, C), dtype=torch.int32, device=dev)
         nbytes = lib.ctn_sisnr_workspace(Bn, C, T)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        _chk(source, estimate, lengths)
+        _chk(source, estimate)
+        _chk_aux(lengths)
         lib.call("ctn_sisnr_pit_fwd", _p(source), _p(estimate), _p(lengths), _p(p32), p32.shape[0], Bn, C, T,
                  _p(max_snr), _p(idx), _p(loss), 0, _p(coef), _p(jsel), _p(ws), nbytes, _stream())
         ctx.mark_dirty(estimate)

@@ -178,3 +178,9 @@ def test_input_dtype_and_layout_are_normalised():
         assert torch.equal(m(wide.to(DEV)[:, ::2]), ref)                      # strided view
     with pytest.raises(ValueError):
         m(torch.zeros(1, 10, device=DEV))
+
+
+def test_double_precision_model_is_rejected_not_reinterpreted():
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV).double()
+    with pytest.raises(ctn.CtnError, match="fp32"):
+        m(torch.zeros(1, 400, device=DEV))
