@@ -13,7 +13,7 @@ for d in sys.argv[1:]:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg[name]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for k, cs in agg.items():
-            if len(cs["_dur_us"]) < 24:
+            if len(cs["_dur_us"]) < 10:
                 continue
             print(k)
             for c, v in sorted(cs.items()):

@@ -38,9 +38,10 @@ struct Tile {
     static constexpr int MT = WM / 32, NTL = WN / 32;
     static constexpr int LDA = BM_ + 4, LDB = BN_ + 4, LDS_ST = WN + 4;
     static constexpr int MAIN_FLOATS = 2 * BK_ * (LDA + LDB);
-    static constexpr int STAGE_FLOATS = 4 * 32 * LDS_ST;
+    static constexpr int NW = WGM_ * WGN_, NTH = 64 * NW;          // waves / threads per workgroup
+    static constexpr int STAGE_FLOATS = NW * 32 * LDS_ST;
     static constexpr int SMEM_FLOATS = MAIN_FLOATS > STAGE_FLOATS ? MAIN_FLOATS : STAGE_FLOATS;
-    static_assert(WGM_ * WGN_ == 4 && WM % 32 == 0 && WN % 32 == 0, "4 waves of 32x32 MFMA tiles");
+    static_assert((NW == 4 || NW == 8) && WM % 32 == 0 && WN % 32 == 0, "4 or 8 waves of 32x32 MFMA tiles");
 };
 using T128x128 = Tile<128, 128, 2, 2>;
 using T128x64 = Tile<128, 64, 2, 2>;
@@ -50,6 +51,8 @@ using T128x64w = Tile<128, 64, 4, 1>;
 using T64x64k32 = Tile<64, 64, 2, 2, 32>;
 using T128x64k32 = Tile<128, 64, 2, 2, 32>;
 using T128x128k32 = Tile<128, 128, 2, 2, 32>;
+using T128x128w8 = Tile<128, 128, 2, 4>;      // 8 waves, each 64x32 (split-bf16 kernels only)
+using T128x64w8 = Tile<128, 64, 4, 2>;        // 8 waves, each 32x32
 
 struct PwArgs {
     const float* W;      // TRANS_W=0: [R, Cn]   TRANS_W=1: [Cn, R]
@@ -199,8 +202,8 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         __builtin_amdgcn_wave_barrier();
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
-        const double d1 = block_sum<double, NT>((double)s1, red);
-        const double d2 = block_sum<double, NT>((double)s2, red);
+        const double d1 = block_sum<double, TL::NTH>((double)s1, red);
+        const double d2 = block_sum<double, TL::NTH>((double)s2, red);
         if (tid == 0) {
             double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
                           ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 2;
@@ -371,12 +374,17 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 // prologue).  A fragments are 16-byte row reads; B fragments (contraction = channels, strided in memory) come
 // out of ds_read_b64_tr_b16, the hardware transpose read, from channel-major LDS planes.
 // ===========================================================================================
-constexpr int XK = 32;            // channels per k-tile (two 16-deep MFMA steps)
+#ifndef CTN_XK
+#define CTN_XK 32
+#endif
+constexpr int XK = CTN_XK;        // channels per k-tile (XK/16 MFMA steps of depth 16)
+constexpr int XAT = XK / 8;       // threads per 16-byte-chunked weight row
 #ifndef CTN_X6_PF
 #define CTN_X6_PF 2
 #endif
 constexpr int X6_PF = CTN_X6_PF;
-constexpr int XPA = 40;           // A-plane row pitch in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
+constexpr int XPA = XK + 8;       // A-plane row pitch in bf16 (80 B / 144 B: conflict-free ds_read_b128 over 16 rows)
+constexpr int WXK = 32, WXPA = 40;   // weight-gradient kernel: 32 frames per k-tile
 
 template <typename TL>
 struct X6 {
@@ -395,15 +403,18 @@ struct X6Args {
 };
 
 template <typename TL, int PRO, int EPI>
-__global__ __launch_bounds__(NT, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192) ? 2 : 1))
+__global__ __launch_bounds__(TL::NTH, TL::NW == 8 ? 2 : ((TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192) ? 2 : 1)))
 void pw_gemm_x6_kernel(X6Args xa) {
     const PwArgs& a = xa.p;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN;
     constexpr int PB = X6<TL>::PB;
-    constexpr int A_L = TM / 64;                  // 16-byte loads per thread per plane (4 threads per row of 32 k)
-    constexpr int B_L = TN / 32;                  // float4 loads per thread (TN/4 threads per channel row)
+    constexpr int NTH = TL::NTH;
+    constexpr int A_L = TM * XAT / NTH;           // 16-byte loads per thread per plane (XAT threads per weight row)
+    constexpr int B_L = XK * TN / 4 / NTH;        // float4 loads per thread (TN/4 threads per channel row)
+    constexpr int AR = NTH / XAT, BR = NTH / (TN / 4);   // rows covered per pass
+    static_assert(A_L >= 1 && B_L >= 1, "tile too small for the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[X6<TL>::SMEM_BYTES];
-    __shared__ double red[NT / 64];
+    __shared__ double red[NTH / 64];
     __bf16* const Ap = reinterpret_cast<__bf16*>(smem_raw);                  // [3][TM][XPA]
     __bf16* const Bp = Ap + X6<TL>::A_ELEMS;                                 // [3][XK][PB]
 
@@ -418,7 +429,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
 
     float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
     if constexpr (PRO == PRO_PRELU_NORM) {
-        finalize_stats<NT>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts,
+        finalize_stats<NTH>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts,
                            (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
         p_alpha = a.pro_alpha[0];
         if (a.pro_ms_out != nullptr && rt == 0 && ct == 0 && tid == 0) {
@@ -434,9 +445,9 @@ void pw_gemm_x6_kernel(X6Args xa) {
     bool a_ok[A_L];
 #pragma unroll
     for (int j = 0; j < A_L; ++j) {
-        const int r = r0 + (tid >> 2) + 64 * j;
+        const int r = r0 + tid / XAT + AR * j;
         a_ok[j] = r < a.R;
-        a_src[j] = xa.Wp + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (tid & 3) * 8;
+        a_src[j] = xa.Wp + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (tid % XAT) * 8;
     }
     const float* b_src[B_L];
     int b_ch[B_L];
@@ -444,7 +455,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
     const bool b_kok = b_k < a.Kp;
 #pragma unroll
     for (int j = 0; j < B_L; ++j) {
-        b_ch[j] = tid / (TN / 4) + (1024 / TN) * j;
+        b_ch[j] = tid / (TN / 4) + BR * j;
         b_src[j] = Xm + (size_t)b_ch[j] * a.Kp + (b_kok ? b_k : 0);
     }
     const size_t b_step = (size_t)XK * a.Kp;
@@ -475,13 +486,13 @@ void pw_gemm_x6_kernel(X6Args xa) {
     auto write_lds = [&](const uint4 (&ra)[3][A_L], const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
-            const int r = (tid >> 2) + 64 * j, c = (tid & 3) * 8;
+            const int r = tid / XAT + AR * j, c = (tid % XAT) * 8;
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = ra[p][j];
         }
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
-            const int i = tid / (TN / 4) + (1024 / TN) * j, k = (tid % (TN / 4)) * 4;
+            const int i = tid / (TN / 4) + BR * j, k = (tid % (TN / 4)) * 4;
             float4 v = rb[j];
             if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
             bf16x4 q1, q2, q3;
@@ -508,7 +519,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
 
     auto compute = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < XK / 16; ++ks) {
         bf16x8 af[MT][3], bfr[NTL][3];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -544,7 +555,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
     float4 pb[B_L];
     float2 pp[B_L];
     load_regs(0, pa, pb, pp);
-    if constexpr (X6_PF == 1) {
+    if constexpr (X6_PF == 1 || TL::NW == 8) {      // 8-wave tiles: one staging set keeps two workgroups per CU
         for (int kt = 0; kt < nk; ++kt) {
             write_lds(pa, pb, pp);
             __syncthreads();
@@ -602,8 +613,9 @@ void pw_gemm_p6_kernel(P6Args xa) {
     const PwArgs& a = xa.p;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN;
     constexpr int PB = X6<TL>::PB;
-    constexpr int A_L = TM / 64;                  // 16-byte loads per thread per plane (4 threads per row of 32 k)
-    constexpr int B_L = TN / 64;                  // 16-byte loads per thread per plane (TN/8 threads per channel row)
+    constexpr int A_L = TM * XAT / NT;            // 16-byte loads per thread per plane (XAT threads per weight row)
+    constexpr int B_L = XK * (TN / 8) / NT;       // 16-byte loads per thread per plane (TN/8 threads per channel row)
+    constexpr int AR = NT / XAT;
     constexpr int BT = TN / 8;                    // threads per channel row
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[X6<TL>::SMEM_BYTES];
     __shared__ double red[NT / 64];
@@ -617,15 +629,19 @@ void pw_gemm_p6_kernel(P6Args xa) {
     const int ct = bid % a.tiles_c;
     const int m = bid / a.tiles_c;
     const int r0 = rt * TM, c0 = ct * TN;
+#ifdef CTN_SKIP_MAINLOOP
+    const int nk = 0;      // diagnostic build: fixed cost of launch + prologue + epilogue only
+#else
     const int nk = xa.Cnp / XK;
+#endif
 
     const __bf16* a_src[A_L];
     bool a_ok[A_L];
 #pragma unroll
     for (int j = 0; j < A_L; ++j) {
-        const int r = r0 + (tid >> 2) + 64 * j;
+        const int r = r0 + tid / XAT + AR * j;
         a_ok[j] = r < a.R;
-        a_src[j] = xa.Wp + (size_t)m * xa.w_m_stride + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (tid & 3) * 8;
+        a_src[j] = xa.Wp + (size_t)m * xa.w_m_stride + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (tid % XAT) * 8;
     }
     const int b_k = c0 + (tid % BT) * 8;
     const bool b_kok = b_k < a.Kp;
@@ -663,7 +679,7 @@ void pw_gemm_p6_kernel(P6Args xa) {
     auto write_lds = [&]() {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
-            const int r = (tid >> 2) + 64 * j, c = (tid & 3) * 8;
+            const int r = tid / XAT + AR * j, c = (tid % XAT) * 8;
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = ra[p][j];
         }
@@ -693,7 +709,7 @@ void pw_gemm_p6_kernel(P6Args xa) {
         __syncthreads();
         if (kt + 1 < nk) load_regs(kt + 1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < XK / 16; ++ks) {
             bf16x8 af[MT][3], bfr[NTL][3];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -888,8 +904,8 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
 // are split while staged and both fragments are plain 16-byte row reads.  128x128 (o x i) tile, 32 frames per k-tile.
 template <int PRO>
 __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ap[3 * BM * XPA];
-    __shared__ __attribute__((aligned(16))) __bf16 Bp[3 * BN * XPA];
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[3 * BM * WXPA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bp[3 * BN * WXPA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bid = blockIdx.x;
@@ -912,9 +928,9 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
     // staging map: 8 threads per row (32 frames = 8 float4), 32 rows per pass, 4 passes for 128 rows
     float4 ra[4], rb[4];
     float2 rg[4];
-    const int nk = (ke - kb + XK - 1) / XK;
+    const int nk = (ke - kb + WXK - 1) / WXK;
     auto load_regs = [&](int kt) {
-        const int k = kb + kt * XK + (tid & 7) * 4;
+        const int k = kb + kt * WXK + (tid & 7) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = (tid >> 3) + 32 * j;
@@ -935,9 +951,9 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
     auto write_one = [&](__bf16* P, int row, int kq, const float4& v) {
         bf16x4 q1, q2, q3;
         split3x4(v, q1, q2, q3);
-        *reinterpret_cast<bf16x4*>(P + (0 * BM + row) * XPA + kq) = q1;
-        *reinterpret_cast<bf16x4*>(P + (1 * BM + row) * XPA + kq) = q2;
-        *reinterpret_cast<bf16x4*>(P + (2 * BM + row) * XPA + kq) = q3;
+        *reinterpret_cast<bf16x4*>(P + (0 * BM + row) * WXPA + kq) = q1;
+        *reinterpret_cast<bf16x4*>(P + (1 * BM + row) * WXPA + kq) = q2;
+        *reinterpret_cast<bf16x4*>(P + (2 * BM + row) * WXPA + kq) = q3;
     };
     auto write_lds = [&](int kt) {
         const int kq = (tid & 7) * 4;
@@ -946,7 +962,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
             const int row = (tid >> 3) + 32 * j;
             write_one(Ap, row, kq, ra[j]);
             if constexpr (PRO == PRO_PRELU_NORM)
-                rb[j] = pro_apply(rb[j], kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
+                rb[j] = pro_apply(rb[j], kb + kt * WXK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
             write_one(Bp, row, kq, rb[j]);
         }
     };
@@ -972,8 +988,8 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * BM + wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
-                    bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bp + (p * BN + wn * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * BM + wm * 64 + i * 32 + l31) * WXPA + ks * 16 + lhi * 8);
+                    bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bp + (p * BN + wn * 64 + i * 32 + l31) * WXPA + ks * 16 + lhi * 8);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1026,11 +1042,12 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
 }  // namespace
 
 // ---- tile selection ------------------------------------------------------------------------
-// id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32
+// id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32,
+//     8 / 9 = 128x128 / 128x64 with 8 waves (split-bf16 kernels only; the fp32 kernels map them to 0 / 1)
 static int g_tile_override = -2;   // -2: not read yet, -1: heuristic
 
 static void tile_dims(int id, int* tm, int* tn) {
-    static const int d[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}};
+    static const int d[10][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}};
     *tm = d[id][0];
     *tn = d[id][1];
 }
@@ -1039,7 +1056,7 @@ static int pick_tile(int M, int R, int Kp) {
     if (g_tile_override == -2) {
         const char* e = getenv("CTN_PW_TILE");
         g_tile_override = (e && *e) ? atoi(e) : -1;
-        if (g_tile_override < -1 || g_tile_override > 7) g_tile_override = -1;
+        if (g_tile_override < -1 || g_tile_override > 9) g_tile_override = -1;
     }
     if (g_tile_override >= 0) return g_tile_override;
     // Measured on MI355X (benchmarks/gemm_sweep.py, paper shapes): 64x64 tiles win every variant -- 3200 / 1600
@@ -1074,7 +1091,7 @@ static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool sta
     a.tiles_r = ctn_cdiv(a.R, tm);
     a.tiles_c = ctn_cdiv(a.Kp, tn);
     switch (id) {
-        case 1: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 1: case 9: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 2: launch_tile<T64x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 3: launch_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 4: launch_tile<T128x64w>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
@@ -1089,7 +1106,7 @@ extern "C" {
 
 // experiment / autotune hook: force a tile id (0..4) for every ctn_pw_gemm / ctn_pw_dgrad_gln, -1 = heuristic
 int ctn_tune_pw_tile(int id) {
-    if (id < -1 || id > 7) return CTN_ERR_ARG;
+    if (id < -1 || id > 9) return CTN_ERR_ARG;
     g_tile_override = id;
     return CTN_OK;
 }
@@ -1233,7 +1250,7 @@ int ctn_split_bf16(const float* W, void* planes, int rows, int cols, int transpo
 template <typename TL>
 static void launch_x6(const X6Args& xa, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     const PwArgs& a = xa.p;
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(NT);
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, xa);
     else if (pro) {
         if (residual) hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, xa);
@@ -1252,6 +1269,8 @@ static void dispatch_x6(X6Args& xa, bool pro, bool residual, bool stats, bool re
     a.tiles_r = ctn_cdiv(a.R, tm);
     a.tiles_c = ctn_cdiv(a.Kp, tn);
     switch (id) {
+        case 8: launch_x6<T128x128w8>(xa, pro, residual, stats, relu, gln_bwd, st); break;
+        case 9: launch_x6<T128x64w8>(xa, pro, residual, stats, relu, gln_bwd, st); break;
         case 0: case 7: launch_x6<T128x128>(xa, pro, residual, stats, relu, gln_bwd, st); break;
         case 1: case 4: case 6: launch_x6<T128x64>(xa, pro, residual, stats, relu, gln_bwd, st); break;
         case 2: launch_x6<T64x128>(xa, pro, residual, stats, relu, gln_bwd, st); break;
@@ -1310,7 +1329,7 @@ static void wgrad_x6_plan(int M, int R, int Cn, int Kp, int* chunk, int* chunks_
     const int max_cpm = ctn_cdiv(Kp, 256);
     if (cpm > max_cpm) cpm = max_cpm;
     if (cpm < 1) cpm = 1;
-    int c = ctn_cdiv(ctn_cdiv(Kp, cpm), XK) * XK;
+    int c = ctn_cdiv(ctn_cdiv(Kp, cpm), WXK) * WXK;
     *chunk = c;
     *chunks_per_m = ctn_cdiv(Kp, c);
 }
@@ -1399,7 +1418,9 @@ int ctn_pw_gemm_p6(const void* Wp, int w_per_m, const void* Xp, float* Out, void
     xa.Cnp = ctn_split_cols(Cn);
     xa.Wp = (const __bf16*)Wp; xa.w_plane_stride = (size_t)R * xa.Cnp; xa.w_m_stride = w_per_m ? 3 * xa.w_plane_stride : 0;
     xa.Xp = (const __bf16*)Xp; xa.x_plane_stride = (size_t)M * Cn * Kp;
-    const int id = pick_tile(M, R, Kp);
+    int id = pick_tile(M, R, Kp);
+    if (id == 8) id = 0;          // the 8-wave tiles exist for the on-the-fly kernel only
+    if (id == 9) id = 1;
     int tm, tn;
     tile_dims(id, &tm, &tn);
     a.tiles_r = ctn_cdiv(R, tm);
