@@ -44,6 +44,27 @@ __global__ __launch_bounds__(256) void probe16(const float* __restrict__ in, flo
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// bf16 32x32x16: NACC independent accumulators, each receiving CHAIN back-to-back dependent MFMAs per iteration
+template <int NACC, int CHAIN>
+__global__ __launch_bounds__(256) void probe_bf16(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)in[(threadIdx.x + e) & 511]; b[e] = (__bf16)in[(threadIdx.x + 17 * e) & 511]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int c = 0; c < CHAIN; ++c) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 static float time_ms(F f) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -85,6 +106,16 @@ int main() {
         const double f32 = (double)blocks * 4 * iters * 4 * 4096.0;          // same FLOPs in every variant
         printf("%d wave(s)/SIMD: 32x32x2 1 chain %.1f TF | 2 chains %.1f TF | 16x16x4 4 chains %.1f TF | 16x16x4 1 chain %.1f TF\n", bpc,
                f32 / m1 / 1e9, f32 / m2 / 1e9, f32 / m4 / 1e9, f32 / m8 / 1e9);
+    }
+    // bf16 32x32x16: dependent-chain experiment (random operands).  FLOPs per MFMA = 2*32*32*16 = 32768
+    for (int bpc = 1; bpc <= 4; bpc *= 2) {
+        const int blocks = 256 * bpc, iters = 20000;
+        const double fl = (double)blocks * 4 * iters * 6 * 32768.0;     // 6 MFMAs per iteration in every variant
+        float t1 = time_ms([&] { hipLaunchKernelGGL((probe_bf16<1, 6>), dim3(blocks), dim3(256), 0, 0, in, out, iters); });
+        float t2 = time_ms([&] { hipLaunchKernelGGL((probe_bf16<2, 3>), dim3(blocks), dim3(256), 0, 0, in, out, iters); });
+        float t6 = time_ms([&] { hipLaunchKernelGGL((probe_bf16<6, 1>), dim3(blocks), dim3(256), 0, 0, in, out, iters); });
+        printf("bf16 32x32x16, %d wave(s)/SIMD: 1 acc x 6-chain %.0f TF | 2 acc x 3-chain %.0f TF | 6 independent acc %.0f TF\n", bpc,
+               fl / t1 / 1e9, fl / t2 / 1e9, fl / t6 / 1e9);
     }
     return 0;
 }
