@@ -53,6 +53,7 @@ using T128x64k32 = Tile<128, 64, 2, 2, 32>;
 using T128x128k32 = Tile<128, 128, 2, 2, 32>;
 using T128x128w8 = Tile<128, 128, 2, 4>;      // 8 waves, each 64x32 (split-bf16 kernels only)
 using T128x64w8 = Tile<128, 64, 4, 2>;        // 8 waves, each 32x32
+using T128x64w8k32 = Tile<128, 64, 4, 2, 32>; // the fp32 kernel needs a 32-deep k-tile to give 512 threads a float4 each
 
 struct PwArgs {
     const float* W;      // TRANS_W=0: [R, Cn]   TRANS_W=1: [Cn, R]
@@ -214,13 +215,15 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
 }
 
 template <typename TL, int TRANS_W, int PRO, int EPI>
-__global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
+__global__ __launch_bounds__(TL::NTH) void pw_gemm_kernel(PwArgs a) {
     constexpr int TM = TL::TM, TN = TL::TN, LDA = TL::LDA, LDB = TL::LDB, MT = TL::MT, NTL = TL::NTL;
     constexpr int WM = TL::WM, WN = TL::WN, BK = TL::TK;
-    constexpr int A_L = TM * BK / 1024, B_L = TN * BK / 1024;    // float4 loads per thread per k-tile
+    constexpr int NTH = TL::NTH;
+    constexpr int A_L = TM * BK / 4 / NTH, B_L = TN * BK / 4 / NTH;    // float4 loads per thread per k-tile
     constexpr int AT = BK / 4;                                  // threads per weight row (TRANS_W = 0)
     __shared__ __attribute__((aligned(16))) float smem[TL::SMEM_FLOATS];
-    __shared__ double red[NT / 64];
+    __shared__ double red[NTH / 64];
+    static_assert(A_L >= 1 && B_L >= 1, "k-tile too small for the workgroup");
     float* const As = smem;                       // [2][BK][LDA]
     float* const Bs = smem + 2 * BK * LDA;        // [2][BK][LDB]
 
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 
     float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
     if constexpr (PRO == PRO_PRELU_NORM) {
-        finalize_stats<NT>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts,
+        finalize_stats<NTH>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts,
                            (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
         p_alpha = a.pro_alpha[0];
         if (a.pro_ms_out != nullptr && rt == 0 && ct == 0 && tid == 0) {
@@ -245,9 +248,9 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
     }
 
     // ---- global -> register staging maps (float4 each) ---------------------------------------
-    // A (weights): TRANS_W=0 reads W[r][c..c+3]: c4 = tid&3, r = tid>>2 (+64 j)
-    //              TRANS_W=1 reads W[c][r..r+3]: r4 = tid % (TM/4), c = tid / (TM/4) (+ (1024/TM) j)
-    // B (activations): X[i][k..k+3]:            k4 = tid % (TN/4), i = tid / (TN/4) (+ (1024/TN) j)
+    // A (weights): TRANS_W=0 reads W[r][c..c+3]: c4 = tid % AT, r = tid / AT (+ (NTH/AT) j)
+    //              TRANS_W=1 reads W[c][r..r+3]: r4 = tid % (TM/4), c = tid / (TM/4) (+ (4 NTH/TM) j)
+    // B (activations): X[i][k..k+3]:            k4 = tid % (TN/4), i = tid / (TN/4) (+ (4 NTH/TN) j)
     const int nk = (a.Cn + BK - 1) / BK;
 
     // PRO: the raw tile and its (gamma, beta) stay in registers across the MFMA phase; the norm is applied when the
@@ -258,17 +261,17 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
         for (int j = 0; j < A_L; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (TRANS_W == 0) {
-                const int r = r0 + tid / AT + (NT / AT) * j, c = kc + (tid % AT) * 4;
+                const int r = r0 + tid / AT + (NTH / AT) * j, c = kc + (tid % AT) * 4;
                 if (r < a.R && c < a.Cn) v = ld4(a.W + (size_t)r * a.Cn + c);
             } else {
-                const int c = kc + tid / (TM / 4) + (1024 / TM) * j, r = r0 + (tid % (TM / 4)) * 4;
+                const int c = kc + tid / (TM / 4) + (4 * NTH / TM) * j, r = r0 + (tid % (TM / 4)) * 4;
                 if (c < a.Cn && r < a.R) v = ld4(a.W + (size_t)c * a.R + r);
             }
             ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
-            const int i = kc + tid / (TN / 4) + (1024 / TN) * j, k = c0 + (tid % (TN / 4)) * 4;
+            const int i = kc + tid / (TN / 4) + (4 * NTH / TN) * j, k = c0 + (tid % (TN / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             float2 gb = make_float2(0.f, 0.f);
             if (i < a.Cn && k < a.Kp) {
@@ -285,19 +288,19 @@ __global__ __launch_bounds__(NT) void pw_gemm_kernel(PwArgs a) {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
             if constexpr (TRANS_W == 0) {
-                const int r = tid / AT + (NT / AT) * j, c = (tid % AT) * 4;
+                const int r = tid / AT + (NTH / AT) * j, c = (tid % AT) * 4;
                 Ab[(c + 0) * LDA + r] = ra[j].x;
                 Ab[(c + 1) * LDA + r] = ra[j].y;
                 Ab[(c + 2) * LDA + r] = ra[j].z;
                 Ab[(c + 3) * LDA + r] = ra[j].w;
             } else {
-                const int c = tid / (TM / 4) + (1024 / TM) * j, r = (tid % (TM / 4)) * 4;
+                const int c = tid / (TM / 4) + (4 * NTH / TM) * j, r = (tid % (TM / 4)) * 4;
                 *reinterpret_cast<float4*>(Ab + c * LDA + r) = ra[j];
             }
         }
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
-            const int i = tid / (TN / 4) + (1024 / TN) * j, k = (tid % (TN / 4)) * 4;
+            const int i = tid / (TN / 4) + (4 * NTH / TN) * j, k = (tid % (TN / 4)) * 4;
             float4 v = rb[j];
             if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
             *reinterpret_cast<float4*>(Bb + i * LDB + k) = v;
@@ -1043,7 +1046,7 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
 
 // ---- tile selection ------------------------------------------------------------------------
 // id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32,
-//     8 / 9 = 128x128 / 128x64 with 8 waves (split-bf16 kernels only; the fp32 kernels map them to 0 / 1)
+//     8 / 9 = 128x128 / 128x64 with 8 waves (512 threads; the fp32 128x64 variant uses BK = 32)
 static int g_tile_override = -2;   // -2: not read yet, -1: heuristic
 
 static void tile_dims(int id, int* tm, int* tn) {
@@ -1070,7 +1073,7 @@ static int pick_tile(int M, int R, int Kp) {
 template <typename TL>
 static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd,
                         hipStream_t st) {
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(NT);
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
         if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
@@ -1091,7 +1094,9 @@ static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool sta
     a.tiles_r = ctn_cdiv(a.R, tm);
     a.tiles_c = ctn_cdiv(a.Kp, tn);
     switch (id) {
-        case 1: case 9: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 1: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 8: launch_tile<T128x128w8>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 9: launch_tile<T128x64w8k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 2: launch_tile<T64x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 3: launch_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 4: launch_tile<T128x64w>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
