@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("CTN_BENCH_GRAPH", "0")),
+                    help="1: replay zero_grad+fwd+loss+bwd from one captured HIP graph (conv_tasnet_amd.graphed)")
     ap.add_argument("--gemm", choices=["fp32", "x6"], default=None,
                     help="1x1-conv arithmetic: fp32 MFMA (default, bit-exact fp32 chains) or split-bf16 emulation (experimental)")
     args = ap.parse_args()
@@ -125,11 +127,19 @@ def main():
     mix, lens, src = mix.to(device), lens.to(device), src.to(device)
     loss_acc = torch.zeros((), device=device)
 
+    graphed = None
+    if args.graph:
+        from conv_tasnet_amd.graphed import GraphedBackprop
+        graphed = GraphedBackprop(model, opt, (mix, lens, src))
+
     def step():
-        opt.zero_grad()
-        est = model(mix)
-        loss, _, _, _ = ctn.cal_loss(src, est, lens)
-        loss.backward()
+        if graphed is not None:
+            loss = graphed(mix, lens, src)
+        else:
+            opt.zero_grad()
+            est = model(mix)
+            loss, _, _, _ = ctn.cal_loss(src, est, lens)
+            loss.backward()
         scale = parallel.allreduce_gradients(opt)
         opt.step(max_grad_norm=5.0, grad_scale=scale)
         loss_acc.add_(loss.detach())
@@ -167,7 +177,7 @@ def main():
                                    "%d x 4s@8kHz utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam" % PER_GPU_BATCH,
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": T_SAMPLES,
                        "parallelism": "dp%d" % world},
-            "gemm_mode": __import__("conv_tasnet_amd").ops.gemm_mode(),
+            "gemm_mode": __import__("conv_tasnet_amd").ops.gemm_mode(), "hip_graph": bool(args.graph),
             "mean_loss": round(mean_loss, 4), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
             "model_tflops": round(value * ftrain / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),

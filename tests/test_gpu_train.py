@@ -184,3 +184,43 @@ def test_double_precision_model_is_rejected_not_reinterpreted():
     m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV).double()
     with pytest.raises(ctn.CtnError, match="fp32"):
         m(torch.zeros(1, 400, device=DEV))
+
+
+def test_graphed_backprop_replays_the_eager_step():
+    """HIP-graph replay of zero_grad+fwd+loss+bwd gives bit-identical gradients and parameter trajectories."""
+    from conv_tasnet_amd.graphed import GraphedBackprop
+    from conv_tasnet_amd.train import SyntheticLoader
+    cfg = dict(N=64, L=20, B=32, H=64, P=3, X=3, R=2, C=2)
+    batches = list(SyntheticLoader(3, 2, samples=8000))
+
+    def run(graph):
+        torch.manual_seed(3)
+        model = ctn.ConvTasNet(**cfg).to(DEV)
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        stepper = GraphedBackprop(model, opt, batches[0]) if graph else None
+        losses, grads = [], []
+        for mix, lens, src in batches:
+            mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
+            if graph:
+                loss = stepper(mix, lens, src)
+            else:
+                opt.zero_grad()
+                loss = ctn.cal_loss(src, model(mix), lens)[0]
+                loss.backward()
+            losses.append(float(loss.detach()))
+            opt.step(max_grad_norm=5.0)
+            grads.append(opt.flat_grads.clone())
+        return losses, grads, opt.flat_params.clone()
+
+    l0, g0, p0 = run(False)
+    l1, g1, p1 = run(True)
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert torch.equal(p0, p1)
+    with pytest.raises(ValueError):
+        torch.manual_seed(3)
+        model = ctn.ConvTasNet(**cfg).to(DEV)
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        st = GraphedBackprop(model, opt, batches[0])
+        st(batches[0][0][:1].to(DEV), batches[0][1][:1].to(DEV), batches[0][2][:1].to(DEV))
