@@ -78,3 +78,29 @@ def test_eval_dataset_and_wav_reader(tmp_path):
     assert names[0].endswith("m1.wav") and abs(float(mix.abs().max())) <= 0.5 + 1e-4
     with pytest.raises(ValueError):
         D.read_wav(str(tmp_path / "m0.wav"), 16000)
+
+
+def test_preprocess_writes_reference_format_manifests(tmp_path):
+    """tr/cv/tt x mix/s1/s2 json lists of [abs path, n_samples] (src/preprocess.py:12-36), readable by AudioDataset."""
+    import json
+    from scipy.io import wavfile
+    from conv_tasnet_amd.preprocess import preprocess
+    from conv_tasnet_amd.data import AudioDataset
+    rs = np.random.RandomState(1)
+    lens = {"a.wav": 33000, "b.wav": 40000, "c.wav": 9000}
+    for split in ("tr", "cv", "tt"):
+        for spk in ("mix", "s1", "s2"):
+            d = tmp_path / "wav" / split / spk
+            d.mkdir(parents=True)
+            for name, n in lens.items():
+                wavfile.write(str(d / name), 8000, (rs.uniform(-0.3, 0.3, n) * 32767).astype(np.int16))
+            (d / "notes.txt").write_text("ignored")
+    preprocess(str(tmp_path / "wav"), str(tmp_path / "json"), 8000)
+    got = json.load(open(tmp_path / "json" / "tr" / "s2.json"))
+    assert sorted((os.path.basename(p), n) for p, n in got) == sorted(lens.items())
+    assert all(os.path.isabs(p) for p, _ in got)
+    ds = AudioDataset(str(tmp_path / "json" / "tr"), batch_size=3, sample_rate=8000, segment=4.0)
+    mix, lengths, src = ds.collate([ds[0]])
+    assert mix.shape[1] == 32000 and src.shape[1:] == (2, 32000) and int(lengths[0]) == 32000
+    with pytest.raises(ValueError):
+        preprocess(str(tmp_path / "wav"), str(tmp_path / "json16"), 16000)
