@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libctn_hip.so")
-SOURCES = ["ctn_api.hip", "ctn_gemm.hip", "ctn_tcn.hip", "ctn_codec.hip", "ctn_loss.hip", "ctn_optim.hip"]
+SOURCES = ["ctn_api.hip", "ctn_gemm.hip", "ctn_tcn.hip", "ctn_bn.hip", "ctn_codec.hip", "ctn_loss.hip", "ctn_optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("CTN_EXTRA_HIPCC_FLAGS", "").split()
 
 

@@ -275,9 +275,11 @@ class TemporalBlock(nn.Module):
             fn = ops.GlnBlock
         elif self.norm_type == "cLN":
             fn = ops.ClnBlock
-        else:
-            raise NotImplementedError("norm_type %r has no HIP path (gLN and cLN do; BN is outside the "
-                                      "hot-path scope, see DESIGN.md)" % self.norm_type)
+        else:       # chose_norm's else-branch: BatchNorm1d (src/conv_tasnet.py:305-309)
+            return ops.BnBlock.apply(x, self.net[0].weight, self.net[1].weight, norm1.weight, norm1.bias,
+                                     ds.net[0].weight, ds.prelu().weight, norm2.weight, norm2.bias,
+                                     ds.pointwise().weight, K, self.dilation, self.causal,
+                                     norm1.step_state(), norm2.step_state())
         return fn.apply(x, self.net[0].weight, self.net[1].weight, norm1.gamma, norm1.beta,
                         ds.net[0].weight, ds.prelu().weight, norm2.gamma, norm2.beta, ds.pointwise().weight,
                         K, self.dilation, self.causal)
@@ -331,7 +333,51 @@ def chose_norm(norm_type, channel_size):
     elif norm_type == "cLN":
         return ChannelwiseLayerNorm(channel_size)
     else:
-        return nn.BatchNorm1d(channel_size)   # constructible for checkpoint parity; no HIP path
+        return BatchNorm1d(channel_size)
+
+
+class _BnOnly(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, weight, bias, K, state):
+        y = y.contiguous()
+        out, mr = ops.bn_fwd(y, None, weight, bias, state[0], state[1], state[2], state[3], state[4], K)
+        ctx.save_for_backward(y, weight, mr)
+        ctx.cfg = (K, bool(state[2]))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, weight, mr = ctx.saved_tensors
+        K, training = ctx.cfg
+        dy, dg, db, _ = ops.bn_bwd(_pad_zero_tail(dout.contiguous(), K), y, None, weight, mr, training, K)
+        return dy, dg, db, None, None
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d's parameters, buffers and state-dict keys (what chose_norm returns for norm_type="BN",
+    src/conv_tasnet.py:305-309) over the HIP kernels: statistics per channel over (M, K) of a [M, Ch, K] input."""
+
+    def __init__(self, channel_size):
+        super().__init__(channel_size)      # affine, track_running_stats, eps 1e-5, momentum 0.1: the reference's defaults
+
+    def step_state(self):
+        """(running_mean, running_var, use_batch_stats, eps, momentum) for one forward call; counts the batch."""
+        training = self.training or self.running_mean is None
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:       # cumulative moving average
+                momentum = 1.0 / float(self.num_batches_tracked)
+        update = self.training and self.track_running_stats
+        rm = self.running_mean if (update or not training) else None
+        rv = self.running_var if (update or not training) else None
+        return (rm, rv, training, self.eps, momentum)
+
+    def forward(self, y):
+        if y.dim() != 3:
+            raise ValueError("expected [M, channels, K]")
+        K = y.size(-1)
+        return _BnOnly.apply(_pad_frames(y, K), self.weight, self.bias, K, self.step_state())[..., :K]
 
 
 class _NormParams(nn.Module):

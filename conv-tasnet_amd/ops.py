@@ -431,6 +431,83 @@ class ClnBlock(torch.autograd.Function):
                 _emit(db2.view(1, H, 1), sk[7]), _emit(dW2.view(B, H, 1), sk[8]), None, None, None)
 
 
+def bn_fwd(Y, alpha, weight, bias, running_mean, running_var, training, eps, momentum, K):
+    """(PReLU +) BatchNorm1d over (m, k) per channel -> (out, mr[Ch,2]).  Updates the running statistics in place."""
+    M, Ch, Kp = Y.shape
+    out = torch.empty_like(Y)
+    mr = torch.empty((Ch, 2), dtype=F32, device=Y.device)
+    part = torch.empty((Ch * M * 2,), dtype=F64, device=Y.device) if training else None
+    _chk(Y, alpha, weight, bias, running_mean, running_var)
+    lib.call("ctn_bn_fwd", _p(Y), _p(out), _p(alpha), _p(weight), _p(bias), _p(running_mean), _p(running_var),
+             int(training), float(eps), float(momentum), M, Ch, K, Kp, _p(part), _p(mr), _stream())
+    return out, mr
+
+
+def bn_bwd(dOut, Y, alpha, weight, mr, training, K):
+    """-> dY, dweight[Ch], dbias[Ch], dalpha[1]|None"""
+    M, Ch, Kp = Y.shape
+    dev = Y.device
+    dY = torch.empty_like(Y)
+    part = torch.empty((Ch * M * 2,), dtype=F64, device=dev)
+    coef = torch.empty((Ch, 2), dtype=F32, device=dev)
+    dg = torch.empty((Ch,), dtype=F32, device=dev)
+    db = torch.empty((Ch,), dtype=F32, device=dev)
+    dap = None if alpha is None else torch.empty((M * Ch,), dtype=F32, device=dev)
+    _chk(dOut, Y, alpha, weight, mr)
+    lib.call("ctn_bn_bwd", _p(dOut), _p(Y), _p(dY), _p(alpha), _p(weight), _p(mr), int(training), M, Ch, K, Kp,
+             _p(part), _p(coef), _p(dg), _p(db), _p(dap), _stream())
+    dalpha = None if dap is None else reduce_mid(dap, 1, M * Ch, 1).view(1)
+    return dY, dg, db, dalpha
+
+
+class BnBlock(torch.autograd.Function):
+    """TemporalBlock with norm_type="BN" (src/conv_tasnet.py:218-244,305-309): same chain as ClnBlock with the two
+    norms replaced by (PReLU +) BatchNorm1d.  bn1 / bn2 = (running_mean, running_var, training, eps, momentum)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, a1, g1, b1, D, a2, g2, b2, w2, K, dilation, causal, bn1, bn2):
+        x = _c(x)
+        M, B, Kp = x.shape
+        H = w1.shape[0]
+        if H % 4 or B % 4:
+            raise ValueError("HIP path needs B and H to be multiples of 4")
+        h1, _ = pw_gemm(w1, x, H, B, K)
+        n1, mr1 = bn_fwd(h1, a1, g1, b1, bn1[0], bn1[1], bn1[2], bn1[3], bn1[4], K)
+        d, _ = dw_fwd(n1, D, K, dilation, causal)
+        n2, mr2 = bn_fwd(d, a2, g2, b2, bn2[0], bn2[1], bn2[2], bn2[3], bn2[4], K)
+        out, _ = pw_gemm(w2, n2, B, H, K, residual=x)
+        ctx.save_for_backward(x, h1, n1, d, n2, mr1, mr2, w1, a1, g1, D, a2, g2, w2)
+        ctx.cfg = (K, dilation, causal, bool(bn1[2]), bool(bn2[2]))
+        ctx.sinks = tuple(_sink(p) for p in (w1, a1, g1, b1, D, a2, g2, b2, w2))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, n1, d, n2, mr1, mr2, w1, a1, g1, D, a2, g2, w2 = ctx.saved_tensors
+        K, dilation, causal, tr1, tr2 = ctx.cfg
+        dout = _c(dout)
+        M, B, Kp = x.shape
+        H = w1.shape[0]
+        P = D.shape[-1]
+        dev = x.device
+        dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
+        dW2 = pw_wgrad(dout, n2, B, H, K)
+        dd, dg2, db2, da2 = bn_bwd(dn2, d, a2, g2, mr2, tr2, K)
+        pc = torch.empty((P, M, H), dtype=F32, device=dev)
+        dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+        _chk(dd, n1)
+        lib.call("ctn_dw_bwd", _p(dd), 0, _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 0,
+                 0, 0, 0, 0, 0, 0, 0, 0, 0, _p(pc), 0, _stream())
+        dD = reduce_mid(pc, P, M, H).t().contiguous().view(H, 1, P)
+        dh1, dg1, db1, da1 = bn_bwd(dn1, h1, a1, g1, mr1, tr1, K)
+        dx, _ = pw_gemm(w1, dh1, B, H, K, trans_w=True, residual=dout)
+        dW1 = pw_wgrad(dh1, x, H, B, K)
+        sk = ctx.sinks
+        return (dx, _emit(dW1.view(H, B, 1), sk[0]), _emit(da1, sk[1]), _emit(dg1, sk[2]), _emit(db1, sk[3]),
+                _emit(dD, sk[4]), _emit(da2, sk[5]), _emit(dg2, sk[6]), _emit(db2, sk[7]),
+                _emit(dW2.view(B, H, 1), sk[8]), None, None, None, None, None)
+
+
 # ---------------------------------------------------------------------------------------
 # Backend: (TCN output, mixture_w) -> estimated sources [M, C, T]
 # ---------------------------------------------------------------------------------------

@@ -153,6 +153,24 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
                 const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream);
 int ctn_cln_bwd_blocks(int M, int Kp);
 
+/* ---- BatchNorm1d over (utterances, frames) per channel, optionally behind PReLU ------------------
+ * replaces nn.BatchNorm1d as returned by chose_norm's else-branch, src/conv_tasnet.py:305-309, at its two uses
+ * (:225 after PReLU :224, :260 after PReLU :259).  gamma/beta are nn.BatchNorm1d's weight/bias [Ch].
+ *   training != 0: batch statistics over the M*K valid frames (biased variance for the normalisation); when
+ *     running_mean/running_var are non-NULL they are updated in place with `momentum` (unbiased variance), as
+ *     torch does.  part: [Ch*M*2] fp64 workspace.
+ *   training == 0: normalises with running_mean / running_var.
+ *   alpha != NULL: the input is prelu(Y, alpha) (fused), else Y itself.
+ *   mr [Ch,2] out: the (mean, 1/sqrt(var+eps)) actually used -- saved for ctn_bn_bwd.  Frames >= K are written 0. */
+int ctn_bn_fwd(const float* Y, float* Out, const float* alpha, const float* gamma, const float* beta,
+               float* running_mean, float* running_var, int training, float eps, float momentum,
+               int M, int Ch, int K, int Kp, double* part, float* mr, void* stream);
+/* dY (may alias dOut) = gradient w.r.t. Y (through the PReLU when alpha != NULL); dgamma/dbeta [Ch];
+ * dalpha_part [M*Ch] per-row partials (sum them in order for dalpha);  part [Ch*M*2] fp64 and coef [Ch,2] workspaces. */
+int ctn_bn_bwd(const float* dOut, const float* Y, float* dY, const float* alpha, const float* gamma, const float* mr,
+               int training, int M, int Ch, int K, int Kp, double* part, float* coef, float* dgamma, float* dbeta,
+               float* dalpha_part, void* stream);
+
 /* out[f][i] = sum_r in[f][r][i]  -- fixed-order finish of the per-(m,c) partials above */
 int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void* stream);
 

@@ -62,14 +62,19 @@ class Config:
 def block_keys(cfg: Config, r: int, x: int) -> Dict[str, str]:
     """state_dict keys of TemporalBlock (r, x).  src/conv_tasnet.py:218-278."""
     p = f"separator.network.2.{r}.{x}.net."
+    bn = cfg.norm_type == "BN"         # nn.BatchNorm1d names its affine pair weight / bias (:309)
+    gname, bname = ("weight", "bias") if bn else ("gamma", "beta")
     k = {"w1": p + "0.weight", "a1": p + "1.weight",
-         "g1": p + "2.gamma", "b1": p + "2.beta",
+         "g1": p + "2." + gname, "b1": p + "2." + bname,
          "dw": p + "3.net.0.weight"}
     o = 1 if cfg.causal else 0  # Chomp1d shifts the integer names (:264-269)
     k["a2"] = p + f"3.net.{1 + o}.weight"
-    k["g2"] = p + f"3.net.{2 + o}.gamma"
-    k["b2"] = p + f"3.net.{2 + o}.beta"
+    k["g2"] = p + f"3.net.{2 + o}." + gname
+    k["b2"] = p + f"3.net.{2 + o}." + bname
     k["w2"] = p + f"3.net.{3 + o}.weight"
+    if bn:
+        k["n1"] = p + "2."                  # + running_mean / running_var / num_batches_tracked
+        k["n2"] = p + f"3.net.{2 + o}."
     return k
 
 
@@ -83,18 +88,34 @@ def param_shapes(cfg: Config) -> "Dict[str, Tuple[int, ...]]":
     for r in range(cfg.R):
         for x in range(cfg.X):
             k = block_keys(cfg, r, x)
+            gshape = (cfg.H,) if cfg.norm_type == "BN" else (1, cfg.H, 1)
             s[k["w1"]] = (cfg.H, cfg.B, 1)
             s[k["a1"]] = (1,)
-            s[k["g1"]] = (1, cfg.H, 1)
-            s[k["b1"]] = (1, cfg.H, 1)
+            s[k["g1"]] = gshape
+            s[k["b1"]] = gshape
             s[k["dw"]] = (cfg.H, 1, cfg.P)
             s[k["a2"]] = (1,)
-            s[k["g2"]] = (1, cfg.H, 1)
-            s[k["b2"]] = (1, cfg.H, 1)
+            s[k["g2"]] = gshape
+            s[k["b2"]] = gshape
             s[k["w2"]] = (cfg.B, cfg.H, 1)
     s["separator.network.3.weight"] = (cfg.C * cfg.N, cfg.B, 1)
     s["decoder.basis_signals.weight"] = (cfg.L, cfg.N)
     return s
+
+
+def init_buffers(cfg: Config, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """nn.BatchNorm1d's buffers at construction (norm_type="BN" only): running_mean 0, running_var 1, count 0."""
+    out: Dict[str, torch.Tensor] = {}
+    if cfg.norm_type != "BN":
+        return out
+    for r in range(cfg.R):
+        for x in range(cfg.X):
+            k = block_keys(cfg, r, x)
+            for pre in (k["n1"], k["n2"]):
+                out[pre + "running_mean"] = torch.zeros(cfg.H, dtype=dtype)
+                out[pre + "running_var"] = torch.ones(cfg.H, dtype=dtype)
+                out[pre + "num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    return out
 
 
 def init_params(cfg: Config, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
@@ -114,8 +135,11 @@ def init_params(cfg: Config, seed: int = 0, dtype=torch.float32) -> Dict[str, to
             fan_in, fan_out = shape[1] * rf, shape[0] * rf
             std = math.sqrt(2.0 / (fan_in + fan_out))
             out[name] = (torch.randn(shape, generator=g, dtype=torch.float64) * std).to(dtype)
-        else:
+        elif shape == (1,):
             out[name] = torch.full(shape, 0.25, dtype=dtype)
+        else:                       # BatchNorm1d affine pair: weight 1, bias 0 (dim 1: untouched by the xavier loop)
+            out[name] = torch.ones(shape, dtype=dtype) if name.endswith("weight") else torch.zeros(shape, dtype=dtype)
+    out.update(init_buffers(cfg, dtype))
     return out
 
 
@@ -143,13 +167,35 @@ def gln(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tenso
     return gamma * (y - mu) / torch.sqrt(var + EPS) + beta
 
 
-def norm(cfg: Config, y, gamma, beta):
-    """chose_norm, src/conv_tasnet.py:298-310 (BN is outside the hot-path scope)."""
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1     # nn.BatchNorm1d defaults, which src/conv_tasnet.py:309 takes
+
+
+def bn(y: torch.Tensor, weight, bias, sd, prefix: str, training: bool) -> torch.Tensor:
+    """nn.BatchNorm1d on [M, Ch, K]: statistics per channel over (M, K).  src/conv_tasnet.py:305-309.
+
+    training: batch mean / biased variance normalise; the running pair in ``sd`` is blended in place with the
+    batch mean / UNBIASED variance and the batch counter advances.  eval: the running pair normalises."""
+    rm, rv = sd[prefix + "running_mean"], sd[prefix + "running_var"]
+    if training:
+        n = y.shape[0] * y.shape[2]
+        mu = y.mean(dim=(0, 2))
+        var = ((y - mu.view(1, -1, 1)) ** 2).mean(dim=(0, 2))
+        with torch.no_grad():
+            rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mu.detach().to(rm.dtype))
+            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * (var.detach() * n / max(n - 1, 1)).to(rv.dtype))
+            sd[prefix + "num_batches_tracked"] += 1
+    else:
+        mu, var = rm.to(y.dtype), rv.to(y.dtype)
+    return (y - mu.view(1, -1, 1)) / torch.sqrt(var.view(1, -1, 1) + BN_EPS) * weight.view(1, -1, 1) + bias.view(1, -1, 1)
+
+
+def norm(cfg: Config, y, gamma, beta, sd=None, prefix=None, training=True):
+    """chose_norm, src/conv_tasnet.py:298-310."""
     if cfg.norm_type == "gLN":
         return gln(y, gamma, beta)
     if cfg.norm_type == "cLN":
         return cln(y, gamma, beta)
-    raise NotImplementedError("norm_type %r: only gLN / cLN are on the hot path" % cfg.norm_type)
+    return bn(y, gamma, beta, sd, prefix, training)
 
 
 def prelu(y: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
@@ -180,17 +226,17 @@ def depthwise(y: torch.Tensor, D: torch.Tensor, dilation: int, causal: bool) -> 
     return z
 
 
-def temporal_block(cfg: Config, x: torch.Tensor, sd, r: int, xi: int) -> torch.Tensor:
+def temporal_block(cfg: Config, x: torch.Tensor, sd, r: int, xi: int, training: bool = True) -> torch.Tensor:
     """x + pw2(norm(prelu(dw(norm(prelu(pw1(x)))))))  src/conv_tasnet.py:231-243,265-269."""
     k = block_keys(cfg, r, xi)
     h = pointwise(x, sd[k["w1"]])
-    h = norm(cfg, prelu(h, sd[k["a1"]]), sd[k["g1"]], sd[k["b1"]])
+    h = norm(cfg, prelu(h, sd[k["a1"]]), sd[k["g1"]], sd[k["b1"]], sd, k.get("n1"), training)
     h = depthwise(h, sd[k["dw"]], 2 ** xi, cfg.causal)
-    h = norm(cfg, prelu(h, sd[k["a2"]]), sd[k["g2"]], sd[k["b2"]])
+    h = norm(cfg, prelu(h, sd[k["a2"]]), sd[k["g2"]], sd[k["b2"]], sd, k.get("n2"), training)
     return x + pointwise(h, sd[k["w2"]])
 
 
-def separator(cfg: Config, w: torch.Tensor, sd) -> torch.Tensor:
+def separator(cfg: Config, w: torch.Tensor, sd, training: bool = True) -> torch.Tensor:
     """mixture_w [M,N,K] -> est_mask [M,C,N,K].  src/conv_tasnet.py:198-215.
 
     The first norm is always channel-wise (:172)."""
@@ -198,7 +244,7 @@ def separator(cfg: Config, w: torch.Tensor, sd) -> torch.Tensor:
     y = pointwise(y, sd["separator.network.1.weight"])
     for r in range(cfg.R):
         for xi in range(cfg.X):
-            y = temporal_block(cfg, y, sd, r, xi)
+            y = temporal_block(cfg, y, sd, r, xi, training)
     score = pointwise(y, sd["separator.network.3.weight"])
     M, _, K = score.shape
     score = score.reshape(M, cfg.C, cfg.N, K)
@@ -230,10 +276,12 @@ def decoder(cfg: Config, w: torch.Tensor, mask: torch.Tensor, V: torch.Tensor) -
     return overlap_and_add(fr, cfg.stride)
 
 
-def forward(cfg: Config, sd, mixture: torch.Tensor) -> torch.Tensor:
-    """mixture [M,T] -> est_source [M,C,T], right-padded with zeros.  src/conv_tasnet.py:45-60."""
+def forward(cfg: Config, sd, mixture: torch.Tensor, training: bool = True) -> torch.Tensor:
+    """mixture [M,T] -> est_source [M,C,T], right-padded with zeros.  src/conv_tasnet.py:45-60.
+
+    ``training`` only matters for norm_type="BN" (batch vs running statistics)."""
     w = encoder(mixture, sd["encoder.conv1d_U.weight"], cfg.stride)
-    mask = separator(cfg, w, sd)
+    mask = separator(cfg, w, sd, training)
     est = decoder(cfg, w, mask, sd["decoder.basis_signals.weight"])
     return F.pad(est, (0, mixture.shape[-1] - est.shape[-1]))
 
@@ -332,6 +380,7 @@ def train_step(cfg: Config, sd, opt_state, mixture, source, lengths, lr=1e-3, ma
     """fwd -> loss -> bwd -> clip -> Adam, in place on ``sd``.  Returns loss (python float)."""
     names = list(param_shapes(cfg).keys())
     leaves = {n: sd[n].detach().requires_grad_(True) for n in names}
+    leaves.update({n: v for n, v in sd.items() if n not in leaves})      # BatchNorm buffers, updated in place
     est = forward(cfg, leaves, mixture)
     loss, _, _, _ = cal_loss(source, est, lengths)
     grads = torch.autograd.grad(loss, [leaves[n] for n in names])

@@ -90,6 +90,37 @@ def model_case(name, T, M, lengths, seed, norm_type="gLN", causal=False, mask="r
     save(name, **arrs)
 
 
+def bn_case(name, T, M, seed, causal=False, **hp):
+    """norm_type="BN" (chose_norm's else-branch, src/conv_tasnet.py:305-309): one training-mode forward/backward
+    (batch statistics, running statistics updated) and one eval-mode forward (running statistics)."""
+    torch.manual_seed(seed)
+    model = ConvTasNet(hp["N"], hp["L"], hp["B"], hp["H"], hp["P"], hp["X"], hp["R"], hp["C"],
+                       norm_type="BN", causal=causal, mask_nonlinear="relu")
+    with torch.no_grad():       # move the affine parameters and slopes off their trivial defaults
+        for k, p in model.named_parameters():
+            if p.dim() == 1 and p.numel() > 1:
+                p.add_(0.2 * torch.randn_like(p) if k.endswith("weight") else 0.1 * torch.randn_like(p))
+    mix, lens, src = synth_batch(100 * seed, M, T, C=hp["C"])
+    arrs = {"cfg": cfg_arr(**hp), "norm_type": "BN", "causal": int(causal), "mask_nonlinear": "relu",
+            "mixture": mix, "source": src, "lengths": lens}
+    for k, v in model.state_dict().items():
+        arrs["p0:" + k] = v.clone()
+    model.train()
+    est = model(mix)
+    arrs["est_source_raw"] = est.detach().clone()
+    loss, max_snr, _, _ = cal_loss(src, est, lens)
+    loss.backward()
+    arrs.update(loss=loss.detach(), max_snr=max_snr.detach())
+    for k, v in model.state_dict().items():
+        arrs["p1:" + k] = v.clone()
+    for k, p in model.named_parameters():
+        arrs["g:" + k] = p.grad
+    model.eval()
+    with torch.no_grad():
+        arrs["est_source_eval"] = model(mix).clone()
+    save(name, **arrs)
+
+
 def pit_cases():
     # (a) the reference's own __main__ smoke inputs (src/pit_criterion.py:117-133): seed 123, randint(4)
     torch.manual_seed(123)
@@ -240,6 +271,10 @@ if __name__ == "__main__":
         data_case()
         sys.exit(0)
     tiny = dict(N=64, L=20, B=32, H=64, P=3, X=2, R=2, C=2)
+    if "--bn-only" in sys.argv:
+        bn_case("model_tiny_bn", T=4005, M=3, seed=5, **tiny)
+        bn_case("model_tiny_bn_causal", T=3001, M=2, seed=6, causal=True, **tiny)
+        sys.exit(0)
     model_case("model_tiny_gln", T=4005, M=2, lengths=[4005, 3777], seed=1, with_intermediates=True, **tiny)
     model_case("model_tiny_cln_causal", T=3001, M=2, lengths=[3001, 2500], seed=2, norm_type="cLN", causal=True,
                **tiny)
@@ -247,6 +282,8 @@ if __name__ == "__main__":
                N=32, L=16, B=16, H=32, P=3, X=3, R=1, C=3)
     model_case("model_c3_relu_x4", T=2400, M=1, lengths=[2211], seed=4,
                N=32, L=16, B=16, H=32, P=3, X=4, R=2, C=3)
+    bn_case("model_tiny_bn", T=4005, M=3, seed=5, **tiny)
+    bn_case("model_tiny_bn_causal", T=3001, M=2, seed=6, causal=True, **tiny)
     pit_cases()
     ola_cases()
     init_case()

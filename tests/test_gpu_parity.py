@@ -501,3 +501,90 @@ def test_standalone_global_layer_norm():
     assert rel_err(out, ref) < 2e-6
     with pytest.raises(NotImplementedError):
         gn(y.to(DEV).requires_grad_(True))
+
+
+# ----------------------------------------------------------------------------- BatchNorm variant
+@pytest.mark.parametrize("with_prelu", [True, False])
+@pytest.mark.parametrize("M,Ch,K", [(3, 20, 130), (2, 64, 799), (1, 7, 61)])
+def test_bn_kernels_vs_torch(M, Ch, K, with_prelu):
+    """ctn_bn_fwd / ctn_bn_bwd (training and eval statistics) against torch's batch_norm + prelu on the CPU."""
+    import torch.nn.functional as Fn
+    Kp = ops.padded_frames(K)
+    y = torch.randn(M, Ch, K, generator=g(1)) * 1.7 + 0.3
+    w = 1 + 0.3 * torch.randn(Ch, generator=g(2))
+    b = 0.2 * torch.randn(Ch, generator=g(3))
+    a = torch.tensor([0.17])
+    dout = torch.randn(M, Ch, K, generator=g(4))
+    for training in (True, False):
+        rm, rv = 0.1 * torch.randn(Ch, generator=g(5)), 0.5 + torch.rand(Ch, generator=g(6))
+        yr = y.clone().requires_grad_(True)
+        wr, br, ar = w.clone().requires_grad_(True), b.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        pre = Fn.prelu(yr, ar) if with_prelu else yr
+        ref = Fn.batch_norm(pre, rm_ref, rv_ref, wr, br, training, 0.1, 1e-5)
+        ref.backward(dout)
+        rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+        ad = a.to(DEV) if with_prelu else None
+        out, mr = ops.bn_fwd(pad(y, Kp).to(DEV), ad, w.to(DEV), b.to(DEV), rm_d, rv_d, training, 1e-5, 0.1, K)
+        assert rel_err(out[..., :K], ref) < 1e-5
+        assert float(out[..., K:].abs().max()) == 0.0 if Kp > K else True
+        assert rel_err(rm_d, rm_ref) < 1e-5 and rel_err(rv_d, rv_ref) < 1e-5
+        dy, dg, db, da = ops.bn_bwd(pad(dout, Kp).to(DEV), pad(y, Kp).to(DEV), ad, w.to(DEV), mr, training, K)
+        assert rel_err(dy[..., :K], yr.grad) < 2e-5
+        assert rel_err(dg, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
+        if with_prelu:
+            assert rel_err(da, ar.grad) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["model_tiny_bn", "model_tiny_bn_causal"])
+def test_bn_model_matches_reference_golden(name):
+    """norm_type="BN" end to end against the reference's recorded training step and eval forward."""
+    gd = load_golden(name)
+    N, L, B, H, P, X, R, C = [int(v) for v in gd["cfg"]]
+    m = ctn.ConvTasNet(N, L, B, H, P, X, R, C, norm_type="BN", causal=bool(int(gd["causal"])))
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in gd.items() if k.startswith("p0:")})
+    m = m.to(DEV).train()
+    mix, src, lens = (torch.from_numpy(gd[k]).to(DEV) for k in ("mixture", "source", "lengths"))
+    est = m(mix)
+    assert rel_err(est, torch.from_numpy(gd["est_source_raw"])) < 2e-5
+    loss = ctn.cal_loss(src, est, lens)[0]
+    assert abs(float(loss.detach()) - float(gd["loss"])) < 1e-3        # north-star budget, dB
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, torch.from_numpy(gd["g:" + k])) < 2e-3, k
+    for k, v in m.state_dict().items():                                # running statistics and batch counters
+        ref = torch.from_numpy(gd["p1:" + k])
+        if v.dtype == torch.long:
+            assert int(v) == int(ref), k
+        else:
+            assert rel_err(v, ref) < 1e-5, k
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(mix), torch.from_numpy(gd["est_source_eval"])) < 2e-5
+
+
+def test_bn_trains_with_flat_adam_and_standalone_module():
+    from conv_tasnet_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    m = ctn.ConvTasNet(32, 16, 16, 32, 3, 2, 1, 2, norm_type="BN").to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    mix, lens, src = O.synth_batch(5, 2, 4000)
+    mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
+    cfg = O.Config(32, 16, 16, 32, 3, 2, 1, 2, norm_type="BN")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    state, losses, ref = {}, [], []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = ctn.cal_loss(src, m(mix), lens)[0]
+        loss.backward()
+        opt.step(max_grad_norm=5.0)
+        losses.append(float(loss.detach()))
+        ref.append(O.train_step(cfg, sd, state, mix.cpu(), src.cpu(), lens.cpu()))
+    assert np.abs(np.array(losses) - np.array(ref)).max() < 1e-3
+    bnm = m.separator.network[2][0][0].net[2]
+    assert isinstance(bnm, torch.nn.BatchNorm1d) and int(bnm.num_batches_tracked) == 3
+    x = torch.randn(2, 32, 77, device=DEV)
+    bnm.eval()
+    want = torch.nn.functional.batch_norm(x.cpu(), bnm.running_mean.cpu(), bnm.running_var.cpu(), bnm.weight.detach().cpu(),
+                                          bnm.bias.detach().cpu(), False, 0.1, 1e-5)
+    assert rel_err(bnm(x), want) < 1e-5

@@ -142,3 +142,35 @@ def test_train_steps_follow_reference_solver():
     n = 3
     ep0 = sum(g["iter_losses"][:n]) / (n + 1)
     assert abs(ep0 - float(g["tr_loss"][0])) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["model_tiny_bn", "model_tiny_bn_causal"])
+def test_batchnorm_variant_matches_reference(name):
+    """norm_type="BN": training-mode forward / loss / gradients / running statistics and the eval-mode forward."""
+    g = load_golden(name)
+    cfg = _cfg(g)
+    sd0 = _sd(g, "p0:")
+    shapes = O.param_shapes(cfg)
+    assert [k for k in sd0 if k in shapes] == list(shapes.keys())
+    assert set(sd0) == set(shapes) | set(O.init_buffers(cfg))
+    for k, v in O.init_buffers(cfg).items():
+        assert torch.equal(sd0[k].to(v.dtype), v), k
+    leaves = {k: (v.clone().requires_grad_(True) if k in shapes else v.clone()) for k, v in sd0.items()}
+    mix, src, lens = (torch.from_numpy(g[k]) for k in ("mixture", "source", "lengths"))
+    est = O.forward(cfg, leaves, mix, training=True)
+    ref = torch.from_numpy(g["est_source_raw"])
+    scale = ref.abs().max().item()
+    assert (est - ref).abs().max().item() <= 2e-5 * scale
+    loss, max_snr, _, _ = O.cal_loss(src, est, lens)
+    assert abs(float(loss) - float(g["loss"])) < 2e-4
+    loss.backward()
+    for k in shapes:
+        r = g["g:" + k]
+        d = np.abs(leaves[k].grad.numpy() - r).max()
+        assert d <= 2e-3 * np.abs(r).max() + 1e-7, (k, d)
+    for k in O.init_buffers(cfg):       # running statistics after one batch
+        np.testing.assert_allclose(leaves[k].numpy(), g["p1:" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        ev = O.forward(cfg, leaves, mix, training=False)
+    ref_ev = torch.from_numpy(g["est_source_eval"])
+    assert (ev - ref_ev).abs().max().item() <= 2e-5 * ref_ev.abs().max().item()
