@@ -44,7 +44,7 @@ def main():
     got, _ = ops.pw_gemm(w1, xB[:1].contiguous(), H, B, K)
     err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
     print("mode %s: max rel err of W1.x vs fp64 = %.3e" % (mode, err), flush=True)
-    for tid in ([3, 1, 8, 9] if mode == "x6" else [int(t) for t in os.environ.get("SWEEP_TILES", "0,1,2,3,4,5,6,7,8,9").split(",")]):
+    for tid in ([int(t) for t in os.environ.get("SWEEP_TILES", "3,1,8,9,10").split(",")] if mode == "x6" else [int(t) for t in os.environ.get("SWEEP_TILES", "0,1,2,3,4,5,6,7,8,9").split(",")]):
         ctn.lib.ctn_tune_pw_tile(tid)
         _, st = ops.pw_gemm(w1, xB, H, B, K, epi_alpha=a)
         np2 = ctn.lib.ctn_pw_stats_parts(M, H, Kp)
@@ -65,7 +65,7 @@ def main():
                      "wgrad pro    R256 C512": lambda: ops.pw_wgrad(xB, xH, B, H, K, pro=(g, b, a, ms))}.items():
         us = timeit(fn)
         rows.append((-1, name, us, flop / us / 1e6))
-    names = ["128x128", "128x64", "64x128", "64x64", "128x64w", "64x64k32", "128x64k32", "128x128k32", "128x128w8", "128x64w8", "-"]
+    names = ["128x128", "128x64", "64x128", "64x64", "128x64w", "64x64k32", "128x64k32", "128x128k32", "128x128w8", "128x64w8", "128x128ws", "-"]
     for tid, name, us, tf in rows:
         print("tile %-8s %-24s %8.1f us %7.1f TFLOP/s" % (names[tid], name, us, tf), flush=True)
 

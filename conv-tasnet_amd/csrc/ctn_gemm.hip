@@ -78,6 +78,23 @@ struct PwArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Buffer (SRSRC) loads: 32-bit per-lane byte offset + scalar offset, and the hardware range check returns 0 for any
+// 16-byte access that ends past `bytes` -- no per-load predicates, zero fills or 64-bit address arithmetic in the
+// main loops (VALU instructions do not overlap the MFMAs of the other waves on a SIMD, so every one of them is
+// paid in full; see profiles/README.md).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    // (bit_cast the whole vector: clang lowers __builtin_bit_cast(float, v[i]) of a vector ELEMENT to element 0)
+    const f32x4v f = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  The row tiles that re-read the same
 // activation columns are consecutive tile indices, so give each XCD a contiguous range of tile indices: its private
 // L2 then serves the re-reads instead of the fabric.  Bijective for any grid size; affects speed only.
@@ -125,9 +142,11 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2
 // Each wave transposes its accumulators through a private LDS patch (32 rows at a time) so that global traffic
 // is 16 bytes per lane along frames instead of 64 dword accesses; residual / ReLU / PReLU-statistics / gLN-backward
 // sums are applied on the float4s.  C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-template <typename TL, int EPI>
+// NTHB: threads of the workgroup (>= TL::NTH); waves beyond TL::NW pass active = false, hold no accumulators and only
+// take part in the block-wide sums.
+template <typename TL, int EPI, int NTHB = TL::NTH>
 __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL::MT][TL::NTL], float* smem, double* red,
-                                              int m, int rt, int ct) {
+                                              int m, int rt, int ct, bool active = true) {
     constexpr int MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, TM = TL::TM, TN = TL::TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / TL::WGN, wn = wave % TL::WGN;
@@ -147,6 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     float* const stage = smem + wave * 32 * LST;
     float s1 = 0.f, s2 = 0.f;
     const size_t mbase = (size_t)m * a.R * a.Kp;
+    if (active)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -203,8 +223,8 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         __builtin_amdgcn_wave_barrier();
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
-        const double d1 = block_sum<double, TL::NTH>((double)s1, red);
-        const double d2 = block_sum<double, TL::NTH>((double)s2, red);
+        const double d1 = block_sum<double, NTHB>((double)s1, red);
+        const double d2 = block_sum<double, NTHB>((double)s2, red);
         if (tid == 0) {
             double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
                           ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 2;
@@ -247,39 +267,48 @@ __global__ __launch_bounds__(TL::NTH) void pw_gemm_kernel(PwArgs a) {
         }
     }
 
-    // ---- global -> register staging maps (float4 each) ---------------------------------------
+    // ---- global -> register staging maps (float4 each), as buffer loads ------------------------
     // A (weights): TRANS_W=0 reads W[r][c..c+3]: c4 = tid % AT, r = tid / AT (+ (NTH/AT) j)
     //              TRANS_W=1 reads W[c][r..r+3]: r4 = tid % (TM/4), c = tid / (TM/4) (+ (4 NTH/TM) j)
     // B (activations): X[i][k..k+3]:            k4 = tid % (TN/4), i = tid / (TN/4) (+ (4 NTH/TN) j)
+    // Out-of-range rows of W (TRANS_W=0) / channels of W^T and of X fall past the end of their buffer and read 0.
+    // A tile that overhangs the contraction (Cn % BK != 0, TRANS_W=0) reads the next weight row instead: finite
+    // values that meet all-zero activation rows (their gamma/beta read 0 too), so the products vanish; overhanging
+    // output rows / columns are never stored.
     const int nk = (a.Cn + BK - 1) / BK;
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)a.R * (unsigned)a.Cn * 4u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
+    __amdgpu_buffer_rsrc_t rsG = rsX, rsBt = rsX;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        rsG = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
+        rsBt = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
+    }
+    int voA[A_L], voB[B_L], voP[B_L];
+#pragma unroll
+    for (int j = 0; j < A_L; ++j) {
+        if constexpr (TRANS_W == 0) voA[j] = ((r0 + tid / AT + (NTH / AT) * j) * a.Cn + (tid % AT) * 4) * 4;
+        else voA[j] = ((tid / (TM / 4) + (4 * NTH / TM) * j) * a.R + r0 + (tid % (TM / 4)) * 4) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_L; ++j) {
+        const int i = tid / (TN / 4) + (4 * NTH / TN) * j;
+        voB[j] = (i * a.Kp + c0 + (tid % (TN / 4)) * 4) * 4;
+        voP[j] = i * 4;
+    }
+    const int sA = (TRANS_W == 0 ? BK : BK * a.R) * 4, sB = BK * a.Kp * 4;      // scalar byte steps per k-tile
 
     // PRO: the raw tile and its (gamma, beta) stay in registers across the MFMA phase; the norm is applied when the
     // tile is written to LDS, so the global loads never have a consumer before the compute they overlap with.
     auto load_tile = [&](int kt, float4 (&ra)[A_L], float4 (&rb)[B_L], float2 (&rp)[B_L]) {
-        const int kc = kt * BK;
 #pragma unroll
-        for (int j = 0; j < A_L; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (TRANS_W == 0) {
-                const int r = r0 + tid / AT + (NTH / AT) * j, c = kc + (tid % AT) * 4;
-                if (r < a.R && c < a.Cn) v = ld4(a.W + (size_t)r * a.Cn + c);
-            } else {
-                const int c = kc + tid / (TM / 4) + (4 * NTH / TM) * j, r = r0 + (tid % (TM / 4)) * 4;
-                if (c < a.Cn && r < a.R) v = ld4(a.W + (size_t)c * a.R + r);
-            }
-            ra[j] = v;
-        }
+        for (int j = 0; j < A_L; ++j) ra[j] = buf_ld4(rsW, voA[j], kt * sA);
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
-            const int i = kc + tid / (TN / 4) + (4 * NTH / TN) * j, k = c0 + (tid % (TN / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 gb = make_float2(0.f, 0.f);
-            if (i < a.Cn && k < a.Kp) {
-                v = ld4(Xm + (size_t)i * a.Kp + k);
-                if constexpr (PRO == PRO_PRELU_NORM) gb = make_float2(a.pro_gamma[i], a.pro_beta[i]);
-            }
-            rb[j] = v;
-            rp[j] = gb;
+            rb[j] = buf_ld4(rsX, voB[j], kt * sB);
+            if constexpr (PRO == PRO_PRELU_NORM)
+                rp[j] = make_float2(buf_ld1(rsG, voP[j], kt * BK * 4), buf_ld1(rsBt, voP[j], kt * BK * 4));
+            else
+                rp[j] = make_float2(0.f, 0.f);
         }
     };
     auto store_tile = [&](int buf, const float4 (&ra)[A_L], const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
@@ -593,6 +622,270 @@ void pw_gemm_x6_kernel(X6Args xa) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) hi[i][j][e] += lo[i][j][e];
     gemm_epilogue<TL, EPI>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+}
+
+// -------------------------------------------------------------------------------------------
+// Wave-specialised split-bf16 GEMM ("x6ws"): 128x128 tile, 8 waves, two-stage LDS ring, one barrier per k-tile.
+// Waves 0..3 (one per SIMD) are consumers: fragment reads + MFMAs only, a 64x64 sub-tile each (2x2 MFMA tiles:
+// 12 fragment reads feed 24 MFMAs, half the LDS bytes per MFMA of a 32x32 wave tile).  Waves 4..7 are producers:
+// global -> registers one k-tile ahead -> PReLU+gLN prologue -> exact 3-way bf16 split -> the other LDS stage.
+// The conversion VALU work and the copy latency sit in different waves from the MFMA chains and co-issue with them.
+// -------------------------------------------------------------------------------------------
+#ifdef CTN_WS_STAMPS
+// Diagnostic build only (-DCTN_WS_STAMPS): s_memtime brackets around the phases of the wave-specialised kernel.
+__device__ unsigned long long ctn_ws_dbg[8192];
+__device__ __forceinline__ unsigned long long ws_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define WS_T(var) const unsigned long long var = ws_stamp()
+#define WS_ACC(sum, t1, t0) sum += (t1) - (t0)
+#else
+#define WS_T(var)
+#define WS_ACC(sum, t1, t0)
+#endif
+
+struct X6WS {
+    using TL = T128x128;                                            // consumer layout: 2x2 waves of 64x64
+    static constexpr int TM = 128, TN = 128, NTHB = 512;
+    static constexpr int PB = TN + 32;
+    static constexpr int A_STAGE = 3 * TM * XPA, B_STAGE = 3 * XK * PB;   // bf16 elements
+    static constexpr int STAGE = A_STAGE + B_STAGE;
+    static constexpr int MAIN_BYTES = 2 * STAGE * 2;
+    static constexpr int EPI_BYTES = TL::STAGE_FLOATS * 4;
+    static constexpr int SMEM_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(X6WS::NTHB, 1) void pw_gemm_x6ws_kernel(X6Args xa) {
+    static_assert(XK == 32, "x6ws is laid out for 32-channel k-tiles");
+    using TL = X6WS::TL;
+    const PwArgs& a = xa.p;
+    constexpr int TM = X6WS::TM, TN = X6WS::TN, PB = X6WS::PB, NTHB = X6WS::NTHB;
+    constexpr int NP = 256;                        // producer threads
+    constexpr int A_L = TM * XAT / NP;             // 2: 16-byte loads per producer thread per plane
+    constexpr int B_L = XK * TN / 4 / NP;          // 4: float4 loads per producer thread
+    constexpr int AR = NP / XAT, BR = NP / (TN / 4);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[X6WS::SMEM_BYTES];
+    __shared__ double red[NTHB / 64];
+    __bf16* const S = reinterpret_cast<__bf16*>(smem_raw);          // [2][A planes | B planes]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c;
+    const int m = bid / a.tiles_c;
+    const int r0 = rt * TM, c0 = ct * TN;
+    const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        finalize_stats<NTHB>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts,
+                             (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
+        p_alpha = a.pro_alpha[0];
+        if (a.pro_ms_out != nullptr && rt == 0 && ct == 0 && tid == 0) {
+            a.pro_ms_out[2 * m] = p_mean;
+            a.pro_ms_out[2 * m + 1] = p_rstd;
+        }
+    }
+    const int nk = xa.Cnp / XK;
+
+    f32x16 hi[2][2], lo[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[i][j][e] = 0.f; lo[i][j][e] = 0.f; }
+
+    if (wave >= 4) {
+        // ------------------------------ producers ------------------------------
+        const int ptid = tid - 256;
+        const size_t plane = (size_t)a.R * xa.Cnp;
+        const __bf16* a_src[A_L];
+        bool a_ok[A_L];
+#pragma unroll
+        for (int j = 0; j < A_L; ++j) {
+            const int r = r0 + ptid / XAT + AR * j;
+            a_ok[j] = r < a.R;
+            a_src[j] = xa.Wp + (size_t)(a_ok[j] ? r : 0) * xa.Cnp + (ptid % XAT) * 8;
+        }
+        const int b_k = c0 + (ptid % (TN / 4)) * 4;
+        const bool b_kok = b_k < a.Kp;
+        const int b_ch0 = ptid / (TN / 4);
+        const float* const b_col = Xm + (b_kok ? b_k : 0);
+        struct Regs {
+            uint4 ra[3][A_L];
+            float4 rb[B_L];
+            float2 rp[B_L];
+        };
+        auto load_regs = [&](int kt, Regs& g) {
+            const int kc = kt * XK;
+            // unconditional loads from clamped addresses (rows / channels / columns out of range are zeroed when the
+            // tile is written to LDS): predicated loads would make hipcc wait for ALL outstanding loads at the first use
+#pragma unroll
+            for (int j = 0; j < A_L; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) g.ra[p][j] = *reinterpret_cast<const uint4*>(a_src[j] + p * plane + kc);
+#pragma unroll
+            for (int j = 0; j < B_L; ++j) {
+                const int i = min(kc + b_ch0 + BR * j, a.Cn - 1);
+                g.rb[j] = ld4(b_col + (size_t)i * a.Kp);
+                if constexpr (PRO == PRO_PRELU_NORM) g.rp[j] = make_float2(a.pro_gamma[i], a.pro_beta[i]);
+            }
+        };
+        auto write_lds = [&](int stage, int kt, const Regs& g) {
+            __bf16* const Ap = S + stage * X6WS::STAGE;
+            __bf16* const Bp = Ap + X6WS::A_STAGE;
+#pragma unroll
+            for (int j = 0; j < A_L; ++j) {
+                const int r = ptid / XAT + AR * j, c = (ptid % XAT) * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = a_ok[j] ? g.ra[p][j] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < B_L; ++j) {
+                const int i = b_ch0 + BR * j, k = (ptid % (TN / 4)) * 4;
+                float4 v = g.rb[j];
+                if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, g.rp[j].x, g.rp[j].y, p_alpha, p_mean, p_rstd);
+                if (!(b_kok && kt * XK + i < a.Cn)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bf16x4 q1, q2, q3;
+                split3x4(v, q1, q2, q3);
+                *reinterpret_cast<bf16x4*>(Bp + (0 * XK + i) * PB + k) = q1;
+                *reinterpret_cast<bf16x4*>(Bp + (1 * XK + i) * PB + k) = q2;
+                *reinterpret_cast<bf16x4*>(Bp + (2 * XK + i) * PB + k) = q3;
+            }
+        };
+        // Three register sets rotate: tile t lives in set t % 3, is written to LDS stage t & 1 during the consumers'
+        // pass over tile t-1, and its set is refilled with tile t+3 right away -- every global load has three
+        // k-tiles of MFMA time to land.
+        Regs g0, g1, g2;
+        const int last = nk - 1;        // loads past the end re-read the last tile (never written to LDS): no branches,
+        load_regs(0, g0);               // so hipcc keeps counted vmcnt waits and the prefetch depth survives
+        load_regs(min(1, last), g1);
+        load_regs(min(2, last), g2);
+        write_lds(0, 0, g0);
+        load_regs(min(3, last), g0);
+        __syncthreads();
+        int kt = 0;
+#ifdef CTN_WS_STAMPS
+        unsigned long long p_write = 0, p_load = 0, p_bar = 0;
+        const unsigned long long p_t0 = ws_stamp();
+#endif
+        for (; kt + 3 < nk; kt += 3) {
+            WS_T(s0);
+            write_lds((kt + 1) & 1, kt + 1, g1);
+            WS_T(s1);
+            load_regs(min(kt + 4, last), g1);
+            WS_T(s2);
+            __syncthreads();
+            WS_T(s3);
+            write_lds((kt + 2) & 1, kt + 2, g2);
+            WS_T(s4);
+            load_regs(min(kt + 5, last), g2);
+            WS_T(s5);
+            __syncthreads();
+            WS_T(s6);
+            write_lds((kt + 3) & 1, kt + 3, g0);
+            WS_T(s7);
+            load_regs(min(kt + 6, last), g0);
+            WS_T(s8);
+            __syncthreads();
+            WS_T(s9);
+            WS_ACC(p_write, s1, s0); WS_ACC(p_write, s4, s3); WS_ACC(p_write, s7, s6);
+            WS_ACC(p_load, s2, s1); WS_ACC(p_load, s5, s4); WS_ACC(p_load, s8, s7);
+            WS_ACC(p_bar, s3, s2); WS_ACC(p_bar, s6, s5); WS_ACC(p_bar, s9, s8);
+        }
+#ifdef CTN_WS_STAMPS
+        if (tid == 256 && blockIdx.x < 512) {
+            unsigned long long* d = ctn_ws_dbg + blockIdx.x * 16 + 8;
+            d[0] = ws_stamp() - p_t0; d[1] = p_write; d[2] = p_load; d[3] = p_bar;
+        }
+#endif
+        // tail: consumer passes kt .. nk-1 (one to three of them), tiles kt+1 and kt+2 if they exist
+        if (kt + 1 < nk) write_lds((kt + 1) & 1, kt + 1, g1);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) write_lds((kt + 2) & 1, kt + 2, g2);
+            __syncthreads();
+        }
+        if (kt + 2 < nk) __syncthreads();
+    } else {
+        // ------------------------------ consumers ------------------------------
+        const int wm = wave >> 1, wn = wave & 1;
+        const int l31 = lane & 31, lhi = lane >> 5;
+        const int tr_q = (lane >> 2) & 3, tr_f = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+        typedef bf16x4 __attribute__((address_space(3))) * lds_b4;
+#ifdef CTN_WS_STAMPS
+        unsigned long long c_comp = 0, c_bar = 0;
+        const unsigned long long c_t00 = ws_stamp();
+#endif
+        __syncthreads();
+#ifdef CTN_WS_STAMPS
+        const unsigned long long c_t0 = ws_stamp();
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+            WS_T(c0);
+            const __bf16* const Ap = S + (kt & 1) * X6WS::STAGE;
+            const __bf16* const Bp = Ap + X6WS::A_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < XK / 16; ++ks) {
+                bf16x8 af[2][3], bfr[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * TM + wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const __bf16* base = Bp + (p * XK + ks * 16 + lhi * 8 + tr_q) * PB + wn * 64 + j * 32 + tr_f;
+                        const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base));
+                        const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base + 4 * PB));
+                        bfr[j][p] = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], lo[i][j], 0, 0, 0);
+                        lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], lo[i][j], 0, 0, 0);
+                        hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], hi[i][j], 0, 0, 0);
+                    }
+            }
+            WS_T(c1);
+            __syncthreads();
+            WS_T(c2);
+            WS_ACC(c_comp, c1, c0); WS_ACC(c_bar, c2, c1);
+        }
+#ifdef CTN_WS_STAMPS
+        if (tid == 0 && blockIdx.x < 512) {
+            unsigned long long* d = ctn_ws_dbg + blockIdx.x * 16;
+            d[0] = ws_stamp() - c_t0; d[1] = c_comp; d[2] = c_bar; d[3] = c_t0 - c_t00; d[4] = c_t00;
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hi[i][j][e] += lo[i][j][e];
+    }
+#ifdef CTN_WS_STAMPS
+    const unsigned long long e_t0 = ws_stamp();
+#endif
+    gemm_epilogue<TL, EPI, NTHB>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct, wave < 4);
+#ifdef CTN_WS_STAMPS
+    if (tid == 0 && blockIdx.x < 512) { ctn_ws_dbg[blockIdx.x * 16 + 5] = ws_stamp() - e_t0; ctn_ws_dbg[blockIdx.x * 16 + 6] = ws_stamp(); }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1039,6 +1332,8 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
     CTN_REQUIRE(M > 0 && R > 0 && Cn > 0 && K > 0 && Kp >= K, "%s: bad sizes M=%d R=%d Cn=%d K=%d Kp=%d", fn, M, R, Cn, K, Kp);
     CTN_REQUIRE(Kp % 4 == 0 && R % 4 == 0 && Cn % 4 == 0, "%s: Kp, rows and contraction must be multiples of 4 (Kp=%d R=%d Cn=%d)", fn, Kp, R, Cn);
     CTN_REQUIRE(aligned16(W) && aligned16(X) && aligned16(Out), "%s: pointers must be 16-byte aligned", fn);
+    CTN_REQUIRE((long long)R * Cn * 4 < (1ll << 31) && (long long)(Cn > R ? Cn : R) * Kp * 4 < (1ll << 31),
+                "%s: one weight matrix / one utterance's activations must stay below 2 GiB (32-bit buffer offsets)", fn);
     return CTN_OK;
 }
 
@@ -1047,10 +1342,11 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
 // ---- tile selection ------------------------------------------------------------------------
 // id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32,
 //     8 / 9 = 128x128 / 128x64 with 8 waves (512 threads; the fp32 128x64 variant uses BK = 32)
+//     10 = 128x128 wave-specialised (split-bf16 forward/dgrad kernels only; fp32 kernels map it to 0)
 static int g_tile_override = -2;   // -2: not read yet, -1: heuristic
 
 static void tile_dims(int id, int* tm, int* tn) {
-    static const int d[10][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}};
+    static const int d[11][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}, {128, 128}};
     *tm = d[id][0];
     *tn = d[id][1];
 }
@@ -1059,7 +1355,7 @@ static int pick_tile(int M, int R, int Kp) {
     if (g_tile_override == -2) {
         const char* e = getenv("CTN_PW_TILE");
         g_tile_override = (e && *e) ? atoi(e) : -1;
-        if (g_tile_override < -1 || g_tile_override > 9) g_tile_override = -1;
+        if (g_tile_override < -1 || g_tile_override > 10) g_tile_override = -1;
     }
     if (g_tile_override >= 0) return g_tile_override;
     // Measured on MI355X (benchmarks/gemm_sweep.py, paper shapes): 64x64 tiles win every variant -- 3200 / 1600
@@ -1111,7 +1407,7 @@ extern "C" {
 
 // experiment / autotune hook: force a tile id (0..4) for every ctn_pw_gemm / ctn_pw_dgrad_gln, -1 = heuristic
 int ctn_tune_pw_tile(int id) {
-    if (id < -1 || id > 9) return CTN_ERR_ARG;
+    if (id < -1 || id > 10) return CTN_ERR_ARG;
     g_tile_override = id;
     return CTN_OK;
 }
@@ -1266,6 +1562,19 @@ static void launch_x6(const X6Args& xa, bool pro, bool residual, bool stats, boo
     else hipLaunchKernelGGL((pw_gemm_x6_kernel<TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, xa);
 }
 
+static void launch_x6ws(const X6Args& xa, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const PwArgs& a = xa.p;
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(X6WS::NTHB);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, xa);
+    else if (pro) {
+        if (residual) hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, xa);
+        else hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, xa);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, xa);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, xa);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_NONE, EPI_RELU>), grid, block, 0, st, xa);
+    else hipLaunchKernelGGL((pw_gemm_x6ws_kernel<PRO_NONE, EPI_NONE>), grid, block, 0, st, xa);
+}
+
 static void dispatch_x6(X6Args& xa, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     PwArgs& a = xa.p;
     const int id = pick_tile(a.M, a.R, a.Kp);
@@ -1274,6 +1583,7 @@ static void dispatch_x6(X6Args& xa, bool pro, bool residual, bool stats, bool re
     a.tiles_r = ctn_cdiv(a.R, tm);
     a.tiles_c = ctn_cdiv(a.Kp, tn);
     switch (id) {
+        case 10: launch_x6ws(xa, pro, residual, stats, relu, gln_bwd, st); break;
         case 8: launch_x6<T128x128w8>(xa, pro, residual, stats, relu, gln_bwd, st); break;
         case 9: launch_x6<T128x64w8>(xa, pro, residual, stats, relu, gln_bwd, st); break;
         case 0: case 7: launch_x6<T128x128>(xa, pro, residual, stats, relu, gln_bwd, st); break;
@@ -1282,6 +1592,12 @@ static void dispatch_x6(X6Args& xa, bool pro, bool residual, bool stats, bool re
         default: launch_x6<T64x64>(xa, pro, residual, stats, relu, gln_bwd, st); break;
     }
 }
+
+#ifdef CTN_WS_STAMPS
+extern "C" int ctn_ws_debug_read(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ctn_ws_dbg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 
@@ -1424,7 +1740,7 @@ int ctn_pw_gemm_p6(const void* Wp, int w_per_m, const void* Xp, float* Out, void
     xa.Wp = (const __bf16*)Wp; xa.w_plane_stride = (size_t)R * xa.Cnp; xa.w_m_stride = w_per_m ? 3 * xa.w_plane_stride : 0;
     xa.Xp = (const __bf16*)Xp; xa.x_plane_stride = (size_t)M * Cn * Kp;
     int id = pick_tile(M, R, Kp);
-    if (id == 8) id = 0;          // the 8-wave tiles exist for the on-the-fly kernel only
+    if (id == 8 || id == 10) id = 0;          // the 8-wave tiles exist for the on-the-fly kernel only
     if (id == 9) id = 1;
     int tm, tn;
     tile_dims(id, &tm, &tn);
