@@ -1114,27 +1114,44 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     float4 ra[NL], rb[NL];
     float2 rg[NL];
     const int nk = (ke - kb + WK - 1) / WK;
+    // Buffer loads (see buf_ld4): rows past R / channels past Cn fall off the end of their per-utterance buffer and read
+    // 0 (as do their gamma / beta); the frame offset of a k-tile is a scalar.  Only a k-tile that straddles the end
+    // of the chunk (Kp not a multiple of 16: never with ctn_padded_frames) needs a per-lane mask, under a uniform branch.
+    const __amdgpu_buffer_rsrc_t rsG = make_rsrc(Gm, (unsigned)a.R * (unsigned)a.Kp * 4u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
+    __amdgpu_buffer_rsrc_t rsGa = rsX, rsBe = rsX;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        rsGa = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
+        rsBe = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
+    }
+    int voG[NL], voX[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int row = (tid >> 2) + 64 * j;
+        voG[j] = ((r0 + row) * a.Kp + (tid & 3) * 4) * 4;
+        voX[j] = ((c0 + row) * a.Kp + (tid & 3) * 4) * 4;
+        if constexpr (PRO == PRO_PRELU_NORM)      // per-channel constants: loaded once, not per k-tile
+            rg[j] = make_float2(buf_ld1(rsGa, (c0 + row) * 4, 0), buf_ld1(rsBe, (c0 + row) * 4, 0));
+    }
     auto load_tile = [&](int kt) {
-        const int k = kb + kt * WK + (tid & 3) * 4;
+        const int so = (kb + kt * WK) * 4;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int row = (tid >> 2) + 64 * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < a.R && k < ke) v = ld4(Gm + (size_t)(r0 + row) * a.Kp + k);
-            ra[j] = v;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int c = c0 + row;
-            if (c < a.Cn && k < ke) {
-                x = ld4(Xm + (size_t)c * a.Kp + k);
-                if constexpr (PRO == PRO_PRELU_NORM) rg[j] = make_float2(a.pro_gamma[c], a.pro_beta[c]);
-            } else if constexpr (PRO == PRO_PRELU_NORM) {
-                rg[j] = make_float2(0.f, 0.f);
-            }
-            rb[j] = x;
+            ra[j] = buf_ld4(rsG, voG[j], so);
+            rb[j] = buf_ld4(rsX, voX[j], so);
         }
     };
     auto store_tile = [&](int buf, int kt) {
         const int kq = (tid & 3) * 4;
+        if (kb + (kt + 1) * WK > ke) {            // uniform: the chunk's ragged last k-tile
+            if (kb + kt * WK + kq >= ke) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int row = (tid >> 2) + 64 * j;
