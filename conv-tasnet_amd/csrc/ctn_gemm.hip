@@ -83,6 +83,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 // main loops (VALU instructions do not overlap the MFMAs of the other waves on a SIMD, so every one of them is
 // paid in full; see profiles/README.md).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
@@ -143,8 +144,11 @@ __device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2
 // is 16 bytes per lane along frames instead of 64 dword accesses; residual / ReLU / PReLU-statistics / gLN-backward
 // sums are applied on the float4s.  C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 // NTHB: threads of the workgroup (>= TL::NTH); waves beyond TL::NW pass active = false, hold no accumulators and only
-// take part in the block-wide sums.
-template <typename TL, int EPI, int NTHB = TL::NTH>
+// take part in the block-wide sums.  EXTRAS: per-row bias and bf16-plane output of the pre-split ("p6") kernels.
+// Global traffic goes through buffer descriptors of this utterance's [R, Kp] matrices: rows >= R are dropped /
+// read as 0 by the hardware range check (their accumulators are exact zeros, so the statistics need no row
+// predicate either); only a tile that overhangs Kp -- a uniform condition -- masks its columns per lane.
+template <typename TL, int EPI, int NTHB = TL::NTH, bool EXTRAS = false>
 __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL::MT][TL::NTL], float* smem, double* red,
                                               int m, int rt, int ct, bool active = true) {
     constexpr int MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, TM = TL::TM, TN = TL::TN;
@@ -152,7 +156,6 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     const int wm = wave / TL::WGN, wn = wave % TL::WGN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int r0 = rt * TM, c0 = ct * TN;
-    float* __restrict__ Om = a.Out + (size_t)m * a.R * a.Kp;
     float e_alpha = 0.f, b_mean = 0.f, b_rstd = 1.f;
     if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
     if constexpr (EPI == EPI_GLN_BWD) {
@@ -166,6 +169,18 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     float* const stage = smem + wave * 32 * LST;
     float s1 = 0.f, s2 = 0.f;
     const size_t mbase = (size_t)m * a.R * a.Kp;
+    const unsigned mat_bytes = (unsigned)a.R * (unsigned)a.Kp * 4u;
+    const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, a.store_f32 ? mat_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rsAux = rsOut, rsGam = rsOut;
+    if constexpr (EPI == EPI_RESIDUAL) rsAux = make_rsrc(a.residual + mbase, mat_bytes);
+    if constexpr (EPI == EPI_GLN_BWD) {
+        rsAux = make_rsrc(a.bwd_y + mbase, mat_bytes);
+        rsGam = make_rsrc(a.bwd_gamma, (unsigned)a.R * 4u);
+    }
+    const bool ragged = c0 + TN > a.Kp;     // uniform
+    const int rl0 = lane / C4, cl = (lane % C4) * 4;
+    const int kcol = c0 + wn * WN + cl;
+    const int vo0 = ((r0 + wm * WM + rl0) * a.Kp + kcol) * 4;
     if (active)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -177,13 +192,12 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < 32 / RPP; ++p) {
-            const int rl = p * RPP + lane / C4, cl = (lane % C4) * 4;
-            const int r = r0 + wm * WM + mt * 32 + rl, k = c0 + wn * WN + cl;
+            const int rl = p * RPP + rl0;
+            const int so = (mt * 32 + p * RPP) * a.Kp * 4;                  // scalar byte offset of this pass
             float4 v = *reinterpret_cast<const float4*>(stage + rl * LST + cl);
-            if (r < a.R && k < a.Kp) {
-                const size_t off = (size_t)r * a.Kp + k;
+            if (!ragged || kcol < a.Kp) {
                 if constexpr (EPI == EPI_RESIDUAL) {
-                    const float4 q = ld4(a.residual + mbase + off);
+                    const float4 q = buf_ld4(rsAux, vo0, so);
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
                 if constexpr (EPI == EPI_RELU) {
@@ -196,27 +210,33 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
                 }
                 if constexpr (EPI == EPI_GLN_BWD) {
-                    const float4 y = ld4(a.bwd_y + mbase + off);
-                    const float g = a.bwd_gamma[r];
+                    const float4 y = buf_ld4(rsAux, vo0, so);
+                    const float g = buf_ld1(rsGam, (r0 + wm * WM + rl0) * 4, (mt * 32 + p * RPP) * 4);
                     const float t0 = g * v.x, t1 = g * v.y, t2 = g * v.z, t3 = g * v.w;
                     const float x0 = (prelu_f(y.x, e_alpha) - b_mean) * b_rstd, x1 = (prelu_f(y.y, e_alpha) - b_mean) * b_rstd;
                     const float x2 = (prelu_f(y.z, e_alpha) - b_mean) * b_rstd, x3 = (prelu_f(y.w, e_alpha) - b_mean) * b_rstd;
                     s1 += (t0 + t1) + (t2 + t3);
                     s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
                 }
-                if (a.row_bias != nullptr) {
-                    const float bia = a.row_bias[(size_t)m * a.R + r];
-                    v.x += (k + 0 < a.K) ? bia : 0.f; v.y += (k + 1 < a.K) ? bia : 0.f;
-                    v.z += (k + 2 < a.K) ? bia : 0.f; v.w += (k + 3 < a.K) ? bia : 0.f;
+                if constexpr (EXTRAS) {
+                    const int r = r0 + wm * WM + mt * 32 + rl;
+                    if (a.row_bias != nullptr && r < a.R) {
+                        const float bia = a.row_bias[(size_t)m * a.R + r];
+                        v.x += (kcol + 0 < a.K) ? bia : 0.f; v.y += (kcol + 1 < a.K) ? bia : 0.f;
+                        v.z += (kcol + 2 < a.K) ? bia : 0.f; v.w += (kcol + 3 < a.K) ? bia : 0.f;
+                    }
                 }
-                if (a.store_f32) *reinterpret_cast<float4*>(Om + off) = v;
-                if (a.out_planes != nullptr) {
-                    bf16x4 q1, q2, q3;
-                    split3x4(v, q1, q2, q3);
-                    __bf16* P = reinterpret_cast<__bf16*>(a.out_planes) + mbase + off;
-                    *reinterpret_cast<bf16x4*>(P) = q1;
-                    *reinterpret_cast<bf16x4*>(P + a.out_plane_stride) = q2;
-                    *reinterpret_cast<bf16x4*>(P + 2 * a.out_plane_stride) = q3;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, f32x4v{v.x, v.y, v.z, v.w}), rsOut, vo0, so, 0);
+                if constexpr (EXTRAS) {
+                    const int r = r0 + wm * WM + mt * 32 + rl;
+                    if (a.out_planes != nullptr && r < a.R) {
+                        bf16x4 q1, q2, q3;
+                        split3x4(v, q1, q2, q3);
+                        __bf16* P = reinterpret_cast<__bf16*>(a.out_planes) + mbase + (size_t)r * a.Kp + kcol;
+                        *reinterpret_cast<bf16x4*>(P) = q1;
+                        *reinterpret_cast<bf16x4*>(P + a.out_plane_stride) = q2;
+                        *reinterpret_cast<bf16x4*>(P + 2 * a.out_plane_stride) = q3;
+                    }
                 }
             }
         }
@@ -1041,7 +1061,7 @@ void pw_gemm_p6_kernel(P6Args xa) {
         for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) hi[i][j][e] += lo[i][j][e];
-    gemm_epilogue<TL, EPI>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+    gemm_epilogue<TL, EPI, TL::NTH, true>(a, hi, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
 }
 
 // X [n] fp32 -> planes [3][n] bf16 (n multiple of 4); stand-alone form of what the producers' epilogues emit
