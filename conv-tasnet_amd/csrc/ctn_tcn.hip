@@ -38,7 +38,7 @@ struct DwFwdArgs {
     const float* epi_alpha; double* epi_part;   // [M, H, 2]
 };
 
-template <bool PRO, bool EPI, int FWD_BUF, bool VEC4>
+template <bool PRO, bool EPI, int FWD_BUF, bool VEC4, int PT>      // PT: compile-time kernel size (3) or 0 = a.P at run time
 __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float buf[ROWS][FWD_BUF];
     __shared__ double red[NT / 64];
@@ -63,12 +63,14 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             a.pro_ms_out[2 * m + 1] = rstd;
         }
     }
-    float taps[MAXP];
+    constexpr int NP = PT ? PT : MAXP;
+    const int P_ = PT ? PT : a.P;
+    float taps[NP];
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) taps[j] = (live && j < a.P) ? a.D[(size_t)c * a.P + j] : 0.f;
+    for (int j = 0; j < NP; ++j) taps[j] = (live && j < P_) ? a.D[(size_t)c * P_ + j] : 0.f;
     float e_alpha = 0.f;
     if constexpr (EPI) e_alpha = a.epi_alpha[0];
-    const int halo = (a.P - 1) * a.dil;
+    const int halo = (P_ - 1) * a.dil;
     float s1 = 0.f, s2 = 0.f;
 
     for (int k0 = 0; k0 < a.Kp; k0 += a.seg) {
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
                 const int idx = k - base - a.padl;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int j = 0; j < MAXP; ++j)
-                    if (j < a.P) {
+                for (int j = 0; j < NP; ++j)
+                    if (PT || j < a.P) {
                         const float4 t = *reinterpret_cast<const float4*>(L + idx + j * a.dil);
                         acc.x += taps[j] * t.x; acc.y += taps[j] * t.y; acc.z += taps[j] * t.z; acc.w += taps[j] * t.w;
                     }
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             const int idx = k - base - a.padl;
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < MAXP; ++j)
-                if (j < a.P) acc += taps[j] * L[idx + j * a.dil];
+            for (int j = 0; j < NP; ++j)
+                if (PT || j < a.P) acc += taps[j] * L[idx + j * a.dil];
             if (k >= a.K) acc = 0.f;
             if constexpr (EPI) {
                 const float p = prelu_f(acc, e_alpha);
@@ -166,7 +168,7 @@ struct DwBwdArgs {
     double* sums1_part;    // [M, H, 2]
 };
 
-template <bool FUSED, int BWD_BUF, bool VEC4>
+template <bool FUSED, int BWD_BUF, bool VEC4, int PT>
 __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float bufA[ROWS][BWD_BUF];  // dd
     __shared__ __attribute__((aligned(16))) float bufB[ROWS][BWD_BUF];  // xh1 (FUSED) or x (PLAIN)
@@ -202,14 +204,16 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
         al1 = a.a1[0]; al2 = a.a2[0];
         if (live) { g1 = a.g1[c]; b1 = a.b1[c]; g2 = a.g2[c]; }
     }
-    float taps[MAXP];
+    constexpr int NP = PT ? PT : MAXP;
+    const int P_ = PT ? PT : a.P;
+    float taps[NP];
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) taps[j] = (live && j < a.P) ? a.D[(size_t)c * a.P + j] : 0.f;
-    const int halo = (a.P - 1) * a.dil;
+    for (int j = 0; j < NP; ++j) taps[j] = (live && j < P_) ? a.D[(size_t)c * P_ + j] : 0.f;
+    const int halo = (P_ - 1) * a.dil;
 
-    float dD[MAXP];
+    float dD[NP];
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j) dD[j] = 0.f;
+    for (int j = 0; j < NP; ++j) dD[j] = 0.f;
     float dg2 = 0.f, db2 = 0.f, dal2 = 0.f, dg1 = 0.f, db1 = 0.f, t1 = 0.f, t2 = 0.f;
 
     for (int k0 = 0; k0 < a.Kp; k0 += a.seg) {
@@ -218,9 +222,11 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
         const int baseA = floor4(k0 + a.padl - halo);
         const int baseB = floor4(k0 - a.padl);
         const int nfill = (kend - k0) + halo + 4;
-        for (int j = lane * 4; j < nfill; j += 256) {
-            {
-                const int k = baseA + j;
+        // dd image.  Frames of [k0, kend) belong to this segment: their parameter-gradient sums are taken here, and
+        // when the segment lies inside [0, K) -- a uniform condition -- nothing in the loop is predicated.  The halo
+        // frames on either side are transformed only (the neighbouring segment owns their sums).
+        auto fill_dd = [&](int kb, int ke, const bool own, const bool all_valid) {
+            for (int k = kb + lane * 4; k < ke; k += 256) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live && k >= 0 && k < a.Kp) {
                     v = ld4(dn2 + k);
@@ -230,22 +236,28 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                         const float dd_[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const bool valid = (k + e) < a.K;
+                            const bool valid = all_valid || (k + e) < a.K;
                             const float xh = (prelu_f(dd_[e], al2) - mean2) * rstd2;
                             const float da = rstd2 * (g2 * vv[e] - c1 - xh * c2);
-                            const bool own = valid && (k + e) >= k0 && (k + e) < kend;   // count each frame once
-                            if (own) {
+                            if (own && valid) {
                                 dg2 += vv[e] * xh;
                                 db2 += vv[e];
-                                if (dd_[e] < 0.f) dal2 += da * dd_[e];
+                                dal2 += dd_[e] < 0.f ? da * dd_[e] : 0.f;
                             }
                             vv[e] = valid ? (dd_[e] >= 0.f ? da : al2 * da) : 0.f;
                         }
                         v = make_float4(vv[0], vv[1], vv[2], vv[3]);
                     }
                 }
-                *reinterpret_cast<float4*>(LA + j) = v;
+                *reinterpret_cast<float4*>(LA + (k - baseA)) = v;
             }
+        };
+        const int endA = baseA + ((nfill + 3) & ~3);
+        if (baseA < k0) fill_dd(baseA, k0, false, false);
+        if (kend <= a.K) fill_dd(max(k0, baseA), kend, true, true);
+        else fill_dd(max(k0, baseA), kend, true, false);
+        if (endA > kend) fill_dd(kend, endA, false, false);
+        for (int j = lane * 4; j < nfill; j += 256) {
             {
                 const int k = baseB + j;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -267,8 +279,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 const int ia = k + a.padl - baseA;
                 float accv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < MAXP; ++j)
-                    if (j < a.P) {
+                for (int j = 0; j < NP; ++j)
+                    if (PT || j < a.P) {
                         const float4 t = *reinterpret_cast<const float4*>(LA + ia - j * a.dil);
                         accv[0] += taps[j] * t.x; accv[1] += taps[j] * t.y; accv[2] += taps[j] * t.z; accv[3] += taps[j] * t.w;
                     }
@@ -276,8 +288,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 const float ddv[4] = {dq.x, dq.y, dq.z, dq.w};
                 const int ib = k - a.padl - baseB;
 #pragma unroll
-                for (int j = 0; j < MAXP; ++j)
-                    if (j < a.P) {
+                for (int j = 0; j < NP; ++j)
+                    if (PT || j < a.P) {
                         const float4 xq = *reinterpret_cast<const float4*>(LB + ib + j * a.dil);
                         float xv[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
@@ -308,20 +320,45 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 if (live) *reinterpret_cast<float4*>(dn1 + k) = make_float4(accv[0], accv[1], accv[2], accv[3]);
             }
         } else {
-        for (int k = k0 + lane; k < kend; k += 64) {
+        for (int kg = k0; kg < kend; kg += 64) {
+            const int k = kg + lane;
+            // a 64-frame group whose taps all stay inside [0, K) (uniform test) needs no per-lane predicates
+            if (kg - a.padl >= 0 && kg + 63 - a.padl + halo < a.K && kg + 63 < kend) {
+                float acc = 0.f;
+                const int ia = k + a.padl - baseA, ib = k - a.padl - baseB;
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    if (PT || j < a.P) {
+                        acc += taps[j] * LA[ia - j * a.dil];
+                        float xv = LB[ib + j * a.dil];
+                        if constexpr (FUSED) xv = g1 * xv + b1;
+                        dD[j] += LA[k - baseA] * xv;
+                    }
+                if constexpr (FUSED) {
+                    const float xh1 = LB[k - baseB];
+                    dg1 += acc * xh1;
+                    db1 += acc;
+                    const float t = g1 * acc;
+                    t1 += t;
+                    t2 += t * xh1;
+                }
+                if (live) dn1[k] = acc;
+                continue;
+            }
+            if (k >= kend) continue;
             // input gradient: transposed taps
             float acc = 0.f;
             const int ia = k + a.padl - baseA;
 #pragma unroll
-            for (int j = 0; j < MAXP; ++j)
-                if (j < a.P) acc += taps[j] * LA[ia - j * a.dil];
+            for (int j = 0; j < NP; ++j)
+                if (PT || j < a.P) acc += taps[j] * LA[ia - j * a.dil];
             if (k >= a.K) acc = 0.f;
             // tap gradients
             const float ddk = LA[k - baseA];
             const int ib = k - a.padl - baseB;
 #pragma unroll
-            for (int j = 0; j < MAXP; ++j)
-                if (j < a.P) {
+            for (int j = 0; j < NP; ++j)
+                if (PT || j < a.P) {
                     const int kk = k - a.padl + j * a.dil;
                     float xv = LB[ib + j * a.dil];
                     if constexpr (FUSED) xv = (kk >= 0 && kk < a.K) ? g1 * xv + b1 : 0.f;
@@ -344,8 +381,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
     }
     const size_t MH = (size_t)a.M * a.H, rc = (size_t)m * a.H + c;
 #pragma unroll
-    for (int j = 0; j < MAXP; ++j)
-        if (j < a.P) {
+    for (int j = 0; j < NP; ++j)
+        if (PT || j < a.P) {
             const float v = wave_sum(dD[j]);
             if (live && lane == 0) a.pc[(size_t)j * MH + rc] = v;
         }
@@ -353,11 +390,11 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
         const float v0 = wave_sum(dg2), v1 = wave_sum(db2), v2 = wave_sum(dg1), v3 = wave_sum(db1), v4 = wave_sum(dal2);
         const double w1 = wave_sum((double)t1), w2 = wave_sum((double)t2);
         if (live && lane == 0) {
-            a.pc[(size_t)(a.P + 0) * MH + rc] = v0;
-            a.pc[(size_t)(a.P + 1) * MH + rc] = v1;
-            a.pc[(size_t)(a.P + 2) * MH + rc] = v2;
-            a.pc[(size_t)(a.P + 3) * MH + rc] = v3;
-            a.pc[(size_t)(a.P + 4) * MH + rc] = v4;
+            a.pc[(size_t)(P_ + 0) * MH + rc] = v0;
+            a.pc[(size_t)(P_ + 1) * MH + rc] = v1;
+            a.pc[(size_t)(P_ + 2) * MH + rc] = v2;
+            a.pc[(size_t)(P_ + 3) * MH + rc] = v3;
+            a.pc[(size_t)(P_ + 4) * MH + rc] = v4;
             a.sums1_part[rc * 2] = w1;
             a.sums1_part[rc * 2 + 1] = w2;
         }
@@ -630,17 +667,24 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = (a.dil % 4 == 0) && (a.padl % 4 == 0);
-#define CTN_DW_FWD(P_, E_)                                                                                  \
-    do {                                                                                                    \
-        if (small && vec4) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_S, true>), grid, block, 0, st, a);   \
-        else if (small) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_S, false>), grid, block, 0, st, a);     \
-        else if (vec4) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_L, true>), grid, block, 0, st, a);       \
-        else hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_L, false>), grid, block, 0, st, a);                \
+#define CTN_DW_FWD_P(P_, E_, PT_)                                                                               \
+    do {                                                                                                        \
+        if (small && vec4) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_S, true, PT_>), grid, block, 0, st, a);  \
+        else if (small) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_S, false, PT_>), grid, block, 0, st, a);    \
+        else if (vec4) hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_L, true, PT_>), grid, block, 0, st, a);      \
+        else hipLaunchKernelGGL((dw_fwd_kernel<P_, E_, FWD_BUF_L, false, PT_>), grid, block, 0, st, a);               \
+    } while (0)
+    // kernel size 3 (every configuration of the paper) is compiled in; other sizes take the run-time-P variant
+#define CTN_DW_FWD(P_, E_)                  \
+    do {                                    \
+        if (P == 3) CTN_DW_FWD_P(P_, E_, 3);  \
+        else CTN_DW_FWD_P(P_, E_, 0);         \
     } while (0)
     if (pro_part && epi_part) CTN_DW_FWD(true, true);
     else if (pro_part) CTN_DW_FWD(true, false);
     else if (epi_part) CTN_DW_FWD(false, true);
     else CTN_DW_FWD(false, false);
+#undef CTN_DW_FWD_P
 #undef CTN_DW_FWD
     CTN_CHECK_LAUNCH("ctn_dw_fwd");
     return CTN_OK;
@@ -676,15 +720,21 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     // float4 compute path: faster for the large-halo variant, slower for the small one (its register count costs
     // two workgroups per CU: 76.7 vs 62.3 us measured), so only used there
     const bool vec4 = !small && (a.dil % 4 == 0) && (a.padl % 4 == 0);
-#define CTN_DW_BWD(F_)                                                                                     \
-    do {                                                                                                   \
-        if (small && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, true>), grid, block, 0, st, a);      \
-        else if (small) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, false>), grid, block, 0, st, a);        \
-        else if (vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, true>), grid, block, 0, st, a);          \
-        else hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, false>), grid, block, 0, st, a);                   \
+#define CTN_DW_BWD_P(F_, PT_)                                                                                   \
+    do {                                                                                                        \
+        if (small && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, true, PT_>), grid, block, 0, st, a);      \
+        else if (small) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, false, PT_>), grid, block, 0, st, a);        \
+        else if (vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, true, PT_>), grid, block, 0, st, a);          \
+        else hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, false, PT_>), grid, block, 0, st, a);                   \
+    } while (0)
+#define CTN_DW_BWD(F_)                  \
+    do {                                \
+        if (P == 3) CTN_DW_BWD_P(F_, 3);  \
+        else CTN_DW_BWD_P(F_, 0);         \
     } while (0)
     if (fused) CTN_DW_BWD(true);
     else CTN_DW_BWD(false);
+#undef CTN_DW_BWD_P
 #undef CTN_DW_BWD
     CTN_CHECK_LAUNCH("ctn_dw_bwd");
     return CTN_OK;
