@@ -13,6 +13,7 @@
 // All cross-lane / cross-block sums have a fixed order (no float atomics), so a
 // step is bitwise reproducible run to run.
 #include "ctn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -717,9 +718,9 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     a.sums2_part = sums2_part; a.sums2_nparts = sums2_nparts; a.pc = pc; a.sums1_part = sums1_part;
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
-    // float4 compute path: faster for the large-halo variant, slower for the small one (its register count costs
-    // two workgroups per CU: 76.7 vs 62.3 us measured), so only used there
-    const bool vec4 = !small && (a.dil % 4 == 0) && (a.padl % 4 == 0);
+    // float4 compute path whenever the tap offsets keep 16-byte alignment (dilation and left pad multiples of 4): with the
+    // kernel size compiled in it also wins for the small-patch variant (44.7 vs 48.5 us at dilation 4..32)
+    const bool vec4 = (a.dil % 4 == 0) && (a.padl % 4 == 0);
 #define CTN_DW_BWD_P(F_, PT_)                                                                                   \
     do {                                                                                                        \
         if (small && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, true, PT_>), grid, block, 0, st, a);      \
