@@ -146,7 +146,7 @@ _ws_cache = {}
 # FlatAdam.step()/the gradient all-reduce join the stream again (join_side_stream()).
 _side = {}
 _SIDE_ENABLED = os.environ.get("CTN_SIDE_STREAM", "1") != "0"
-_SIDE_FIN = os.environ.get("CTN_SIDE_FIN", "0") != "0"   # finishing reductions on the side stream: measured slower
+_SIDE_FIN = os.environ.get("CTN_SIDE_FIN", "0") != "0"   # finishing reductions on the side stream too: measured slower (464 vs 490)
 
 
 def _side_stream(device):
@@ -164,14 +164,19 @@ def join_side_stream(device=None):
             torch.cuda.current_stream(dev).wait_stream(st)
 
 
-def _wgrad_async(dOut, X, R, Cn, K, out, pro=None):
-    """pw_wgrad on the side stream, ordered after everything issued so far on the current stream."""
+def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=()):
+    """pw_wgrad on the side stream, ordered after everything issued so far on the current stream.
+
+    first(): other gradient-finishing launches that ride behind the same cross-stream event (each event costs the
+    issuing queue a bubble, so they never get one of their own); first_inputs: the tensors they read."""
     dev = X.device
     side = _side_stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
+        if first is not None:
+            first()
         pw_wgrad(dOut, X, R, Cn, K, pro=pro, out=out, ws_tag="wgrad_side")
-    for t in (dOut, X) + (tuple(pro) if pro is not None else ()):
+    for t in (dOut, X) + (tuple(pro) if pro is not None else ()) + tuple(first_inputs):
         t.record_stream(side)        # the caching allocator must not hand these out before the side stream is done
 
 
@@ -354,14 +359,14 @@ class GlnBlock(torch.autograd.Function):
             dg2, db2, dg1, db1 = (torch.empty((1, H, 1), dtype=F32, device=dev) for _ in range(4))
             da2 = torch.empty((1,), dtype=F32, device=dev)
             da1 = torch.empty((1,), dtype=F32, device=dev)
+        # The fixed-order finishing reductions feed only parameter gradients.  CTN_SIDE_FIN=1 issues them with the first
+        # layer's weight gradient behind the event recorded after B4; the weight-gradient stream is the longer of the
+        # two, so that loses (464 vs 490 utt/s) and they stay on the chain by default.
+        def finish():
+            lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), _stream())
+            reduce_mid(da1p, 1, M * H, 1, out=da1)
         side_fin = side and _SIDE_FIN
-        if side_fin:      # parameter-gradient finishing kernels are off the chain too
-            sst = _side_stream(dev)
-            sst.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(sst):
-                lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), _stream())
-            pc.record_stream(sst)
-        else:
+        if not side_fin:
             lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), st)
         # -- gLN1 + PReLU1 backward, in place on dn1
         da1p = torch.empty((M * H,), dtype=F32, device=dev)
@@ -370,11 +375,10 @@ class GlnBlock(torch.autograd.Function):
             reduce_mid(da1p, 1, M * H, 1, out=da1)
         # -- first 1x1
         if side:
-            _wgrad_async(dn1, x, H, B, K, sinks[0])
             if side_fin:
-                with torch.cuda.stream(sst):
-                    reduce_mid(da1p, 1, M * H, 1, out=da1)
-                da1p.record_stream(sst)
+                _wgrad_async(dn1, x, H, B, K, sinks[0], first=finish, first_inputs=(pc, da1p))
+            else:
+                _wgrad_async(dn1, x, H, B, K, sinks[0])
         dx, _ = pw_gemm(w1, dn1, B, H, K, trans_w=True, residual=dout)
         if not side:
             dW1 = pw_wgrad(dn1, x, H, B, K, out=sinks[0] if direct else None)
