@@ -190,8 +190,16 @@ def _workspace(nbytes, device, tag):
     return buf
 
 
+_wgrad_tuned = False
+
+
 def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None, ws_tag="wgrad"):
     """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2]).  out: optional destination."""
+    global _wgrad_tuned
+    if not _wgrad_tuned:            # tuning knob: target workgroups per launch of the split-K plan (library default 512)
+        _wgrad_tuned = True
+        if os.environ.get("CTN_WGRAD_BLOCKS"):
+            lib.call("ctn_tune_wgrad", 0, int(os.environ["CTN_WGRAD_BLOCKS"]))
     M, _, Kp = X.shape
     dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
     x6 = _GEMM_MODE == "x6"
