@@ -19,7 +19,7 @@ b = torch.randn(1, H, 1, device=dev)
 ms = torch.tensor([[0.1, 1.3]] * M, device=dev)
 flop = 2.0 * H * B * M * K
 ref = torch.einsum("mrk,mck->rc", xH[:2].double().cpu(), xB[:2].double().cpu())
-for tile in (128, 64):
+for tile in (64, 12864, 128):
     for blocks in (256, 384, 512, 768, 1024):
         ctn.lib.ctn_tune_wgrad(tile, blocks)
         got = ops.pw_wgrad(xH[:2].contiguous(), xB[:2].contiguous(), H, B, K)
@@ -27,4 +27,4 @@ for tile in (128, 64):
         t1 = timeit(lambda: ops.pw_wgrad(xH, xB, H, B, K))
         t2 = timeit(lambda: ops.pw_wgrad(xB, xH, B, H, K, pro=(g, b, a, ms)))
         ws = ctn.lib.ctn_pw_wgrad_workspace(M, H, B, Kp) / 2**20
-        print("tile %3d blocks %4d: plain %6.1f us (%5.1f TF)  pro %6.1f us  slabs %5.1f MiB  err %.1e" % (tile, blocks, t1, flop / t1 / 1e6, t2, ws, err), flush=True)
+        print("tile %5d blocks %4d: plain %6.1f us (%5.1f TF)  pro %6.1f us  slabs %5.1f MiB  err %.1e" % (tile, blocks, t1, flop / t1 / 1e6, t2, ws, err), flush=True)

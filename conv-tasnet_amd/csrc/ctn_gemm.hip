@@ -1106,11 +1106,12 @@ struct WgArgs {
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
 };
 
-template <int PRO, int WT>     // WT x WT output tile (128 or 64), waves 2x2
+template <int PRO, int WTM, int WTN>     // WTM x WTN output tile (multiples of 64), waves 2x2, (WTM/64)*(WTN/64) accumulator chains per wave
 __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
-    constexpr int HT = WT / 2, MTW = WT / 64, NL = WT / 64;     // wave tile edge, MFMA tiles per wave edge, loads/thread
-    __shared__ float As[2][WT][LDW];
-    __shared__ float Bs[2][WT][LDW];
+    constexpr int HTM = WTM / 2, HTN = WTN / 2;             // wave tile
+    constexpr int MTM = WTM / 64, MTN = WTN / 64;           // MFMA tiles per wave edge = float4 loads per thread and k-tile
+    __shared__ float As[2][WTM][LDW];
+    __shared__ float Bs[2][WTN][LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bid = blockIdx.x;
@@ -1120,7 +1121,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     const int m = sp / a.chunks_per_m, ch = sp % a.chunks_per_m;
     const int kb = ch * a.chunk;
     const int ke = min(kb + a.chunk, a.Kp);
-    const int r0 = rt * WT, c0 = ct * WT;
+    const int r0 = rt * WTM, c0 = ct * WTN;
     const float* __restrict__ Gm = a.dOut + (size_t)m * a.R * a.Kp;
     const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
 
@@ -1131,8 +1132,8 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         p_alpha = a.pro_alpha[0];
     }
 
-    float4 ra[NL], rb[NL];
-    float2 rg[NL];
+    float4 ra[MTM], rb[MTN];
+    float2 rg[MTN];
     const int nk = (ke - kb + WK - 1) / WK;
     // Buffer loads (see buf_ld4): rows past R / channels past Cn fall off the end of their per-utterance buffer and read
     // 0 (as do their gamma / beta); the frame offset of a k-tile is a scalar.  Only a k-tile that straddles the end
@@ -1144,11 +1145,12 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         rsGa = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
         rsBe = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
     }
-    int voG[NL], voX[NL];
+    int voG[MTM], voX[MTN];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
+    for (int j = 0; j < MTM; ++j) voG[j] = ((r0 + (tid >> 2) + 64 * j) * a.Kp + (tid & 3) * 4) * 4;
+#pragma unroll
+    for (int j = 0; j < MTN; ++j) {
         const int row = (tid >> 2) + 64 * j;
-        voG[j] = ((r0 + row) * a.Kp + (tid & 3) * 4) * 4;
         voX[j] = ((c0 + row) * a.Kp + (tid & 3) * 4) * 4;
         if constexpr (PRO == PRO_PRELU_NORM)      // per-channel constants: loaded once, not per k-tile
             rg[j] = make_float2(buf_ld1(rsGa, (c0 + row) * 4, 0), buf_ld1(rsBe, (c0 + row) * 4, 0));
@@ -1156,39 +1158,41 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     auto load_tile = [&](int kt) {
         const int so = (kb + kt * WK) * 4;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            ra[j] = buf_ld4(rsG, voG[j], so);
-            rb[j] = buf_ld4(rsX, voX[j], so);
-        }
+        for (int j = 0; j < MTM; ++j) ra[j] = buf_ld4(rsG, voG[j], so);
+#pragma unroll
+        for (int j = 0; j < MTN; ++j) rb[j] = buf_ld4(rsX, voX[j], so);
     };
     auto store_tile = [&](int buf, int kt) {
         const int kq = (tid & 3) * 4;
         if (kb + (kt + 1) * WK > ke) {            // uniform: the chunk's ragged last k-tile
             if (kb + kt * WK + kq >= ke) {
 #pragma unroll
-                for (int j = 0; j < NL; ++j) {
-                    ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int j = 0; j < MTM; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < MTN; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
+        for (int j = 0; j < MTM; ++j) {
+            const int row = (tid >> 2) + 64 * j;
+            As[buf][row][kq + 0] = ra[j].x; As[buf][row][kq + 1] = ra[j].y;
+            As[buf][row][kq + 2] = ra[j].z; As[buf][row][kq + 3] = ra[j].w;
+        }
+#pragma unroll
+        for (int j = 0; j < MTN; ++j) {
             const int row = (tid >> 2) + 64 * j;
             if constexpr (PRO == PRO_PRELU_NORM)      // applied here, after the MFMA phase the loads overlapped with
                 rb[j] = pro_apply(rb[j], kb + kt * WK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
-            As[buf][row][kq + 0] = ra[j].x; As[buf][row][kq + 1] = ra[j].y;
-            As[buf][row][kq + 2] = ra[j].z; As[buf][row][kq + 3] = ra[j].w;
             Bs[buf][row][kq + 0] = rb[j].x; Bs[buf][row][kq + 1] = rb[j].y;
             Bs[buf][row][kq + 2] = rb[j].z; Bs[buf][row][kq + 3] = rb[j].w;
         }
     };
 
-    f32x16 acc[MTW][MTW];
+    f32x16 acc[MTM][MTN];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MTM; ++i)
 #pragma unroll
-        for (int j = 0; j < MTW; ++j)
+        for (int j = 0; j < MTN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -1204,16 +1208,15 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int s = 0; s < WK / 2; ++s) {
             const int kk = 2 * s + lhi;
-            float av[MTW], bv[MTW];
+            float av[MTM], bv[MTN];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                av[i] = As[buf][wm * HT + 32 * i + l31][kk];
-                bv[i] = Bs[buf][wn * HT + 32 * i + l31][kk];
-            }
+            for (int i = 0; i < MTM; ++i) av[i] = As[buf][wm * HTM + 32 * i + l31][kk];
 #pragma unroll
-            for (int i = 0; i < MTW; ++i)
+            for (int j = 0; j < MTN; ++j) bv[j] = Bs[buf][wn * HTN + 32 * j + l31][kk];
 #pragma unroll
-                for (int j = 0; j < MTW; ++j)
+            for (int i = 0; i < MTM; ++i)
+#pragma unroll
+                for (int j = 0; j < MTN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
@@ -1221,13 +1224,13 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     }
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+    for (int mt = 0; mt < MTM; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int r = r0 + wm * HT + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            const int r = r0 + wm * HTM + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
 #pragma unroll
-            for (int nt = 0; nt < MTW; ++nt) {
-                const int c = c0 + wn * HT + nt * 32 + l31;
+            for (int nt = 0; nt < MTN; ++nt) {
+                const int c = c0 + wn * HTN + nt * 32 + l31;
                 if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = acc[mt][nt][e];
             }
         }
@@ -1502,14 +1505,23 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
 
 extern "C" {
 
-static int g_wgrad_tile = 0;      // 0: heuristic, 64 or 128: forced (ctn_tune_wgrad)
+static int g_wgrad_tile = 0;      // 0: heuristic; 64, 128: square tiles; 12864: 128 x 64 (ctn_tune_wgrad)
 static int g_wgrad_blocks = 512;   // target workgroups per launch
 
+static void wgrad_tile_dims(int code, int* tm, int* tn) {
+    *tm = code == 12864 ? 128 : code;
+    *tn = code == 12864 ? 64 : code;
+}
+
 static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int* chunks_per_m) {
-    // 64x64 output tiles whenever the matrix has enough of them: 4x fewer split-K slabs than 128x128 for the same
-    // number of workgroups (slab traffic = splits x R x Cn x 4 B, written once and read once by the reduce kernel).
-    int wt = g_wgrad_tile ? g_wgrad_tile : ((R >= 64 && Cn >= 64) ? 64 : 128);
-    const int tiles = ctn_cdiv(R, wt) * ctn_cdiv(Cn, wt);
+    // Small output tiles keep the number of split-K slabs down (slab traffic = splits x R x Cn x 4 B, written once and
+    // read once by the reduce kernel): 128x64 (two accumulator chains per wave, 3 LDS fragment reads per 2 MFMAs)
+    // where the matrix has the rows for it, else 64x64.  In isolation all three tiles run at ~82 us on the paper
+    // shapes; inside the training step, next to the chain kernels, 128x64 is worth +1.3 % (493 vs 487 utt/s).
+    int wt = g_wgrad_tile ? g_wgrad_tile : ((R >= 128 && Cn >= 64) ? 12864 : ((R >= 64 && Cn >= 64) ? 64 : 128));
+    int tm, tn;
+    wgrad_tile_dims(wt, &tm, &tn);
+    const int tiles = ctn_cdiv(R, tm) * ctn_cdiv(Cn, tn);
     int cpm = ctn_cdiv(g_wgrad_blocks, tiles * M);
     const int max_cpm = ctn_cdiv(Kp, 256);         // keep >= 256 frames of contraction per slab
     if (cpm > max_cpm) cpm = max_cpm;
@@ -1521,7 +1533,7 @@ static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int*
 }
 
 int ctn_tune_wgrad(int tile, int blocks) {
-    if (!(tile == 0 || tile == 64 || tile == 128) || blocks < 1) return CTN_ERR_ARG;
+    if (!(tile == 0 || tile == 64 || tile == 128 || tile == 12864) || blocks < 1) return CTN_ERR_ARG;
     g_wgrad_tile = tile;
     g_wgrad_blocks = blocks;
     return CTN_OK;
@@ -1544,7 +1556,9 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     a.dOut = dOut; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     int wt;
     wgrad_plan(M, R, Cn, Kp, &wt, &a.chunk, &a.chunks_per_m);
-    a.tiles_r = ctn_cdiv(R, wt); a.tiles_c = ctn_cdiv(Cn, wt);
+    int wtm, wtn;
+    wgrad_tile_dims(wt, &wtm, &wtn);
+    a.tiles_r = ctn_cdiv(R, wtm); a.tiles_c = ctn_cdiv(Cn, wtn);
     const int nsplit = M * a.chunks_per_m;
     if (workspace == nullptr || workspace_bytes < (size_t)nsplit * R * Cn * sizeof(float)) {
         ctn_set_error("ctn_pw_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)nsplit * R * Cn * sizeof(float));
@@ -1554,11 +1568,14 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(NT);
     if (wt == 64) {
-        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 64>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 64>), grid, block, 0, st, a);
+        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 64, 64>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 64, 64>), grid, block, 0, st, a);
+    } else if (wt == 12864) {
+        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 128, 64>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 128, 64>), grid, block, 0, st, a);
     } else {
-        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 128>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 128>), grid, block, 0, st, a);
+        if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 128, 128>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 128, 128>), grid, block, 0, st, a);
     }
     CTN_CHECK_LAUNCH("ctn_pw_wgrad");
     const long long n = (long long)R * Cn;

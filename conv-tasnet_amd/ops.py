@@ -196,10 +196,10 @@ _wgrad_tuned = False
 def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None, ws_tag="wgrad"):
     """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2]).  out: optional destination."""
     global _wgrad_tuned
-    if not _wgrad_tuned:            # tuning knob: target workgroups per launch of the split-K plan (library default 512)
+    if not _wgrad_tuned:            # tuning knobs of the split-K plan: output tile (64 | 12864 | 128) and target workgroups per launch (512)
         _wgrad_tuned = True
-        if os.environ.get("CTN_WGRAD_BLOCKS"):
-            lib.call("ctn_tune_wgrad", 0, int(os.environ["CTN_WGRAD_BLOCKS"]))
+        if os.environ.get("CTN_WGRAD_BLOCKS") or os.environ.get("CTN_WGRAD_TILE"):
+            lib.call("ctn_tune_wgrad", int(os.environ.get("CTN_WGRAD_TILE", "0")), int(os.environ.get("CTN_WGRAD_BLOCKS", "512")))
     M, _, Kp = X.shape
     dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
     x6 = _GEMM_MODE == "x6"

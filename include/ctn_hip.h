@@ -72,7 +72,7 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
                  const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
                  void* workspace, size_t workspace_bytes, void* stream);
 size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
-/* experiment / autotune hook: output tile edge (0 = heuristic, 64, 128) and target workgroups per launch (default 512);
+/* experiment / autotune hook: output tile (0 = heuristic, 64, 128 square, 12864 = 128 x 64) and target workgroups per launch (default 512);
  * call before sizing workspaces */
 int ctn_tune_wgrad(int tile, int blocks);
 
