@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         p_alpha = a.pro_alpha[0];
     }
 
-    float4 ra[MTM], rb[MTN];
     float2 rg[MTN];
     const int nk = (ke - kb + WK - 1) / WK;
     // Buffer loads (see buf_ld4): rows past R / channels past Cn fall off the end of their per-utterance buffer and read
@@ -1157,14 +1156,14 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         if constexpr (PRO == PRO_PRELU_NORM)      // per-channel constants: loaded once, not per k-tile
             rg[j] = make_float2(buf_ld1(rsGa, (c0 + row) * 4, 0), buf_ld1(rsBe, (c0 + row) * 4, 0));
     }
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, float4 (&ra)[MTM], float4 (&rb)[MTN]) {
         const int so = (kb + kt * WK) * 4;
 #pragma unroll
         for (int j = 0; j < MTM; ++j) ra[j] = buf_ld4(rsG, voG[j], so);
 #pragma unroll
         for (int j = 0; j < MTN; ++j) rb[j] = buf_ld4(rsX, voX[j], so);
     };
-    auto store_tile = [&](int buf, int kt) {
+    auto store_tile = [&](int buf, int kt, float4 (&ra)[MTM], float4 (&rb)[MTN]) {
         const int kq = (tid & 3) * 4;
         if (kb + (kt + 1) * WK > ke) {            // uniform: the chunk's ragged last k-tile
             if (kb + kt * WK + kq >= ke) {
@@ -1199,14 +1198,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int l31 = lane & 31, lhi = lane >> 5;
-    if (nk > 0) {
-        load_tile(0);
-        store_tile(0, 0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < WK / 2; ++s) {
             const int kk = 2 * s + lhi;
@@ -1221,8 +1213,27 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
                 for (int j = 0; j < MTN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1, kt + 1);
+    };
+    // prefetch distance 2, as in pw_gemm_kernel: tile kt+1 waits in one register set, tile kt+2 is in flight into the other
+    float4 pa[MTM], pb[MTN], qa[MTM], qb[MTN];
+    if (nk > 0) {
+        load_tile(0, pa, pb);
+        store_tile(0, 0, pa, pb);
+        if (nk > 1) load_tile(1, pa, pb);
+        if (nk > 2) load_tile(2, qa, qb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);
+        if (kt + 1 < nk) store_tile(1, kt + 1, pa, pb);
         __syncthreads();
+        if (kt + 3 < nk) load_tile(kt + 3, pa, pb);
+        if (kt + 1 < nk) {
+            compute(1);
+            if (kt + 2 < nk) store_tile(0, kt + 2, qa, qb);
+            __syncthreads();
+            if (kt + 4 < nk) load_tile(kt + 4, qa, qb);
+        }
     }
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
@@ -1517,10 +1528,9 @@ static void wgrad_tile_dims(int code, int* tm, int* tn) {
 
 static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int* chunks_per_m) {
     // Small output tiles keep the number of split-K slabs down (slab traffic = splits x R x Cn x 4 B, written once and
-    // read once by the reduce kernel): 128x64 (two accumulator chains per wave, 3 LDS fragment reads per 2 MFMAs)
-    // where the matrix has the rows for it, else 64x64.  In isolation all three tiles run at ~82 us on the paper
-    // shapes; inside the training step, next to the chain kernels, 128x64 is worth +1.3 % (493 vs 487 utt/s).
-    int wt = g_wgrad_tile ? g_wgrad_tile : ((R >= 128 && Cn >= 64) ? 12864 : ((R >= 64 && Cn >= 64) ? 64 : 128));
+    // read once by the reduce kernel).  Measured inside the training step (CTN_WGRAD_TILE / CTN_WGRAD_BLOCKS, one box,
+    // alternating): 64x64 / 512 workgroups 497 utt/s, 128x64 (two accumulator chains per wave) 492, 64x64 / 1024 494.
+    int wt = g_wgrad_tile ? g_wgrad_tile : ((R >= 64 && Cn >= 64) ? 64 : 128);
     int tm, tn;
     wgrad_tile_dims(wt, &tm, &tn);
     const int tiles = ctn_cdiv(R, tm) * ctn_cdiv(Cn, tn);
