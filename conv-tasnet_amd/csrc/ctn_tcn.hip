@@ -64,6 +64,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             a.pro_ms_out[2 * m + 1] = rstd;
         }
     }
+    const float gs = g * rstd, cc = b - gs * mean, gn = gs * alpha;
     constexpr int NP = PT ? PT : MAXP;
     const int P_ = PT ? PT : a.P;
     float taps[NP];
@@ -83,11 +84,17 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live && k >= 0 && k < a.Kp) {
                 v = ld4(y + k);
-                if constexpr (PRO) {
-                    v.x = (k + 0 < a.K) ? g * ((prelu_f(v.x, alpha) - mean) * rstd) + b : 0.f;
-                    v.y = (k + 1 < a.K) ? g * ((prelu_f(v.y, alpha) - mean) * rstd) + b : 0.f;
-                    v.z = (k + 2 < a.K) ? g * ((prelu_f(v.z, alpha) - mean) * rstd) + b : 0.f;
-                    v.w = (k + 3 < a.K) ? g * ((prelu_f(v.w, alpha) - mean) * rstd) + b : 0.f;
+                if constexpr (PRO) {       // gamma*((prelu(x)-mean)*rstd)+beta as one select + one FMA per element
+                    v.x = fmaf(v.x, v.x >= 0.f ? gs : gn, cc);
+                    v.y = fmaf(v.y, v.y >= 0.f ? gs : gn, cc);
+                    v.z = fmaf(v.z, v.z >= 0.f ? gs : gn, cc);
+                    v.w = fmaf(v.w, v.w >= 0.f ? gs : gn, cc);
+                    if (k + 3 >= a.K) {
+                        if (k + 0 >= a.K) v.x = 0.f;
+                        if (k + 1 >= a.K) v.y = 0.f;
+                        if (k + 2 >= a.K) v.z = 0.f;
+                        if (k + 3 >= a.K) v.w = 0.f;
+                    }
                 }
             }
             *reinterpret_cast<float4*>(L + j) = v;
@@ -212,6 +219,9 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
     for (int j = 0; j < NP; ++j) taps[j] = (live && j < P_) ? a.D[(size_t)c * P_ + j] : 0.f;
     const int halo = (P_ - 1) * a.dil;
 
+    // folded constants of the two norms: xh = x*(x>=0 ? rstd : alpha*rstd) - mean*rstd ;  da = rg2*dn2 - rc1 - xh*rc2
+    const float ar1 = al1 * rstd1, mr1 = mean1 * rstd1, ar2 = al2 * rstd2, mr2 = mean2 * rstd2;
+    const float rg2 = rstd2 * g2, rc1 = rstd2 * c1, rc2 = rstd2 * c2;
     float dD[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) dD[j] = 0.f;
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const bool valid = all_valid || (k + e) < a.K;
-                            const float xh = (prelu_f(dd_[e], al2) - mean2) * rstd2;
-                            const float da = rstd2 * (g2 * vv[e] - c1 - xh * c2);
+                            const float xh = fmaf(dd_[e], dd_[e] >= 0.f ? rstd2 : ar2, -mr2);    // (prelu(d)-mean2)*rstd2
+                            const float da = fmaf(-xh, rc2, fmaf(rg2, vv[e], -rc1));            // rstd2*(g2*dn2 - c1 - xh*c2)
                             if (own && valid) {
                                 dg2 += vv[e] * xh;
                                 db2 += vv[e];
@@ -265,10 +275,10 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 if (live && k >= 0 && k < a.Kp) {
                     v = ld4(y1 + k);
                     if constexpr (FUSED) {
-                        v.x = (prelu_f(v.x, al1) - mean1) * rstd1;
-                        v.y = (prelu_f(v.y, al1) - mean1) * rstd1;
-                        v.z = (prelu_f(v.z, al1) - mean1) * rstd1;
-                        v.w = (prelu_f(v.w, al1) - mean1) * rstd1;
+                        v.x = fmaf(v.x, v.x >= 0.f ? rstd1 : ar1, -mr1);
+                        v.y = fmaf(v.y, v.y >= 0.f ? rstd1 : ar1, -mr1);
+                        v.z = fmaf(v.z, v.z >= 0.f ? rstd1 : ar1, -mr1);
+                        v.w = fmaf(v.w, v.w >= 0.f ? rstd1 : ar1, -mr1);
                     }
                 }
                 *reinterpret_cast<float4*>(LB + j) = v;
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
     const double n = (double)H * (double)K;
     const float c1 = (float)(S1 / n), c2 = (float)(S2 / n);
     const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha_p[0], g = gamma[c];
+    const float ar = al * rstd, mr = mean * rstd, rg = rstd * g, rc1 = rstd * c1, rc2 = rstd * c2;
     const size_t row = ((size_t)m * H + c) * Kp;
     float dal = 0.f;
     for (int k = lane * 4; k < Kp; k += 256) {
@@ -436,8 +447,8 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (prelu_f(yv[e], al) - mean) * rstd;
-            const float da = rstd * (g * dv[e] - c1 - xh * c2);
+            const float xh = fmaf(yv[e], yv[e] >= 0.f ? rstd : ar, -mr);
+            const float da = fmaf(-xh, rc2, fmaf(rg, dv[e], -rc1));
             const bool valid = (k + e) < K;
             if (valid && yv[e] < 0.f) dal += da * yv[e];
             o[e] = valid ? (yv[e] >= 0.f ? da : al * da) : 0.f;
