@@ -157,11 +157,26 @@ def _side_stream(device):
     return st
 
 
+# CTN_LIGHT_EVENTS=1: cross-stream ordering through the library's device-scope event (ctn_stream_order) instead of
+# torch's default event.  Measured +0.4 % (500-502 vs 498.5 utt/s): the ~6 us queue bubble per event is not the
+# system-scope fence.  Off by default.
+_LIGHT_EVENTS = os.environ.get("CTN_LIGHT_EVENTS", "0") != "0"
+
+
+def _order(src, dst):
+    """dst waits for everything enqueued on src so far (device-scope event of the library, or torch's default event)."""
+    if _LIGHT_EVENTS:
+        with torch.cuda.device(src.device):
+            lib.call("ctn_stream_order", src.cuda_stream, dst.cuda_stream)
+    else:
+        dst.wait_stream(src)
+
+
 def join_side_stream(device=None):
     """Make the current stream wait for every weight-gradient kernel issued on the side stream."""
     for dev, st in _side.items():
         if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(st)
+            _order(st, torch.cuda.current_stream(dev))
 
 
 def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=()):
@@ -171,7 +186,7 @@ def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=()):
     issuing queue a bubble, so they never get one of their own); first_inputs: the tensors they read."""
     dev = X.device
     side = _side_stream(dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
+    _order(torch.cuda.current_stream(dev), side)
     with torch.cuda.stream(side):
         if first is not None:
             first()

@@ -34,6 +34,10 @@ extern "C" {
 int ctn_version(void);
 const char* ctn_last_error(void);
 int ctn_padded_frames(int K);               /* K rounded up to a multiple of 64 */
+/* Orders two HIP streams of the current device: work enqueued on `from` so far completes before work enqueued on `to`
+ * after the call.  Device-scope event (no timing, no system-scope fence): the cheap form of
+ * torch.cuda.Stream.wait_stream for the weight-gradient stream of the backward pass. */
+int ctn_stream_order(void* from, void* to);
 
 /* ---- 1x1 convolutions = fp32-MFMA GEMMs ------------------------------------------------
  * replaces nn.Conv1d(*, *, 1, bias=False): src/conv_tasnet.py:174 (bottleneck), :191 (mask),
