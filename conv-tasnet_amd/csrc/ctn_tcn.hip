@@ -567,6 +567,132 @@ __global__ __launch_bounds__(NT) void cln_bwd_dx_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident channel-wise LayerNorm: a 1024-thread workgroup owns FR frames x all channels.  Lane l of wave w
+// holds frame l % FR for channel group g = w * (64/FR) + l / FR, i.e. channels g, g + NG, ... (NG = 1024/FR groups,
+// CPT channels per thread), so the tensor is read ONCE for the two-pass statistics and the normalisation (the generic
+// kernels above re-read it per pass with 4 waves per 64 frames: 1.6 TB/s).  FR = 32 keeps 128-byte row segments.
+// ---------------------------------------------------------------------------
+constexpr int CLN_NT = 1024, CLN_FR = 32;
+
+template <int FR, int CPT>
+__global__ __launch_bounds__(CLN_NT) void cln_fwd_reg_kernel(const float* __restrict__ Y, float* __restrict__ Out,
+                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                             int M, int Ch, int K, int Kp, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ alpha_p) {
+    constexpr int NG = CLN_NT / FR;
+    __shared__ float sh[NG][FR];
+    const int fr = threadIdx.x % FR, g = threadIdx.x / FR;
+    const int kb = (Kp + FR - 1) / FR;
+    const int m = blockIdx.x / kb, k = (blockIdx.x % kb) * FR + fr;
+    const bool in = k < Kp;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const float* __restrict__ y = Y + (size_t)m * Ch * Kp + (in ? k : 0);
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + NG * j;
+        float t = (in && c < Ch) ? y[(size_t)c * Kp] : 0.f;
+        if (has_a) t = prelu_f(t, al);
+        v[j] = t;
+        s += t;
+    }
+    sh[g][fr] = s;
+    __syncthreads();
+    float mu = 0.f;
+    for (int w = 0; w < NG; ++w) mu += sh[w][fr];
+    mu /= (float)Ch;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+        if (g + NG * j < Ch) q += (v[j] - mu) * (v[j] - mu);
+    sh[g][fr] = q;
+    __syncthreads();
+    float var = 0.f;
+    for (int w = 0; w < NG; ++w) var += sh[w][fr];
+    var /= (float)Ch;
+    const float rs = 1.0f / sqrtf(var + CTN_EPS);
+    if (!in) return;
+    if (g == 0) {
+        mean_o[(size_t)m * Kp + k] = mu;
+        rstd_o[(size_t)m * Kp + k] = rs;
+    }
+    float* __restrict__ o = Out + (size_t)m * Ch * Kp + k;
+    const bool valid = k < K;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + NG * j;
+        if (c < Ch) o[(size_t)c * Kp] = valid ? gamma[c] * ((v[j] - mu) * rs) + beta[c] : 0.f;
+    }
+}
+
+template <int FR, int CPT>
+__global__ __launch_bounds__(CLN_NT) void cln_bwd_dx_reg_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                                float* __restrict__ dY, const float* __restrict__ mean_i,
+                                                                const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
+                                                                const float* __restrict__ gamma, const float* __restrict__ alpha_p,
+                                                                const float* __restrict__ add, const float* __restrict__ relu_ref,
+                                                                float* __restrict__ dalpha_part) {
+    constexpr int NG = CLN_NT / FR;
+    __shared__ float sh[2][NG][FR];
+    __shared__ float red[CLN_NT / 64];
+    const int fr = threadIdx.x % FR, g = threadIdx.x / FR;
+    const int kb = (Kp + FR - 1) / FR;
+    const int m = blockIdx.x / kb, k = (blockIdx.x % kb) * FR + fr;
+    const bool in = k < Kp, valid = k < K;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const size_t off = (size_t)m * Ch * Kp + (in ? k : 0);
+    const float mu = in ? mean_i[(size_t)m * Kp + k] : 0.f, rs = in ? rstd_i[(size_t)m * Kp + k] : 0.f;
+    float t[CPT], yv[CPT];           // gamma * dOut and the raw input of this thread's channels
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + NG * j;
+        const bool ok = valid && c < Ch;
+        yv[j] = ok ? Y[off + (size_t)c * Kp] : 0.f;
+        t[j] = ok ? gamma[c] * dOut[off + (size_t)c * Kp] : 0.f;
+        const float v = has_a ? prelu_f(yv[j], al) : yv[j];
+        s1 += t[j];
+        s2 += ok ? t[j] * ((v - mu) * rs) : 0.f;
+    }
+    sh[0][g][fr] = s1;
+    sh[1][g][fr] = s2;
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+    for (int w = 0; w < NG; ++w) { m1 += sh[0][w][fr]; m2 += sh[1][w][fr]; }
+    m1 /= (float)Ch;
+    m2 /= (float)Ch;
+    float dal = 0.f;
+    if (in) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = g + NG * j;
+            if (c < Ch) {
+                const size_t o = off + (size_t)c * Kp;
+                float r = 0.f;
+                if (valid) {
+                    const float v = has_a ? prelu_f(yv[j], al) : yv[j];
+                    const float xh = (v - mu) * rs;
+                    const float da = rs * (t[j] - m1 - xh * m2);
+                    if (has_a && yv[j] < 0.f) dal += da * yv[j];
+                    r = (has_a && yv[j] < 0.f) ? al * da : da;
+                    if (add != nullptr) r += add[o];
+                    if (relu_ref != nullptr && !(relu_ref[o] > 0.f)) r = 0.f;
+                }
+                dY[o] = r;
+            }
+        }
+    }
+    if (dalpha_part != nullptr) {
+        dal = block_sum<float, CLN_NT>(dal, red);
+        if (threadIdx.x == 0) dalpha_part[blockIdx.x] = dal;
+    }
+}
+
 // per-(m,c) partial of dgamma = sum_k dOut*xh and dbeta = sum_k dOut ; pc[2][M][Ch]
 __global__ __launch_bounds__(NT) void cln_bwd_params_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
@@ -779,13 +905,23 @@ int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int
                 const float* gamma, const float* beta, const float* alpha, void* stream) {
     CTN_REQUIRE(Y && Out && mean && rstd && gamma && beta, "ctn_cln_fwd: null pointer");
     CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K, "ctn_cln_fwd: bad sizes");
-    hipLaunchKernelGGL(cln_fwd_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, (hipStream_t)stream,
-                       Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid_r((unsigned)(M * ctn_cdiv(Kp, CLN_FR)));
+#define CTN_CLN_FWD(CPT_) hipLaunchKernelGGL((cln_fwd_reg_kernel<CLN_FR, CPT_>), grid_r, dim3(CLN_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha)
+    const int cpt = ctn_cdiv(Ch, CLN_NT / CLN_FR);
+    if (cpt <= 2) CTN_CLN_FWD(2);
+    else if (cpt <= 4) CTN_CLN_FWD(4);
+    else if (cpt <= 8) CTN_CLN_FWD(8);
+    else if (cpt <= 16) CTN_CLN_FWD(16);
+    else if (cpt <= 32) CTN_CLN_FWD(32);
+    else hipLaunchKernelGGL(cln_fwd_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp,
+                            gamma, beta, alpha);
+#undef CTN_CLN_FWD
     CTN_CHECK_LAUNCH("ctn_cln_fwd");
     return CTN_OK;
 }
 
-int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, 64); }
+int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, CLN_FR); }   // >= the generic kernel's M * ceil(Kp/64)
 
 // dalpha_part: [ctn_cln_bwd_blocks] (only when alpha != NULL); pc: [2, M, Ch]
 int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
@@ -800,8 +936,20 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     hipLaunchKernelGGL(cln_bwd_params_kernel, dim3((unsigned)(M * ctn_cdiv(Ch, ROWS))), dim3(NT), 0, st,
                        dOut, Y, mean, rstd, M, Ch, K, Kp, alpha, pc);
     CTN_CHECK_LAUNCH("ctn_cln_bwd/params");
-    hipLaunchKernelGGL(cln_bwd_dx_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st,
-                       dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, alpha ? dalpha_part : nullptr);
+    const dim3 grid_r((unsigned)(M * ctn_cdiv(Kp, CLN_FR)));
+    float* const dap = alpha ? dalpha_part : nullptr;
+#define CTN_CLN_BWD(CPT_) hipLaunchKernelGGL((cln_bwd_dx_reg_kernel<CLN_FR, CPT_>), grid_r, dim3(CLN_NT), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap)
+    const int cpt = ctn_cdiv(Ch, CLN_NT / CLN_FR);
+    if (cpt <= 2) CTN_CLN_BWD(2);
+    else if (cpt <= 4) CTN_CLN_BWD(4);
+    else if (cpt <= 8) CTN_CLN_BWD(8);
+    else if (cpt <= 16) CTN_CLN_BWD(16);
+    else {      // more than 512 channels: generic kernel; it fills only the first M*ceil(Kp/64) partials of the buffer
+        if (dap) hipMemsetAsync(dap, 0, sizeof(float) * (size_t)ctn_cln_bwd_blocks(M, Kp), st);
+        hipLaunchKernelGGL(cln_bwd_dx_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st, dOut, Y, dY, mean, rstd, M,
+                           Ch, K, Kp, gamma, alpha, add, relu_ref, dap);
+    }
+#undef CTN_CLN_BWD
     CTN_CHECK_LAUNCH("ctn_cln_bwd/dx");
     return CTN_OK;
 }
