@@ -34,6 +34,7 @@ t0 = time.perf_counter()
 n = 10
 for _ in range(n):
     step()
+t_issue = (time.perf_counter() - t0) / n
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print("%s causal=%d: %.2f ms/step, %.1f utt/s" % (norm, causal, dt * 1e3, 8 / dt))
+print("%s causal=%d: %.2f ms/step, %.1f utt/s (host issue %.2f ms/step)" % (norm, causal, dt * 1e3, 8 / dt, t_issue * 1e3))

@@ -245,8 +245,9 @@ def cln_fwd(Y, gamma, beta, alpha, K):
     return out, mean, rstd
 
 
-def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None):
-    """-> dY, dgamma[Ch], dbeta[Ch], dalpha[1]|None"""
+def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None, sinks=None):
+    """-> dY, dgamma[Ch], dbeta[Ch], dalpha[1]|None.  sinks = (dgamma, dbeta, dalpha) destinations (FlatAdam's flat
+    gradient views): the fixed-order finishing reductions then write there directly and None is returned for them."""
     M, Ch, Kp = Y.shape
     dY = torch.empty_like(Y)
     pc = torch.empty((2, M, Ch), dtype=F32, device=Y.device)
@@ -256,6 +257,12 @@ def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None):
     _chk(dOut, Y, mean, rstd, gamma, alpha, add, relu_ref)
     lib.call("ctn_cln_bwd", _p(dOut), _p(Y), _p(dY), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(alpha),
              _p(add), _p(relu_ref), _p(dap), _p(pc), _stream())
+    if sinks is not None:
+        reduce_mid(pc[0], 1, M, Ch, out=sinks[0])
+        reduce_mid(pc[1], 1, M, Ch, out=sinks[1])
+        if dap is not None:
+            reduce_mid(dap, 1, dap.numel(), 1, out=sinks[2])
+        return dY, None, None, None
     red = reduce_mid(pc, 2, M, Ch)
     dalpha = None if dap is None else reduce_mid(dap, 1, dap.numel(), 1).view(1)
     return dY, red[0], red[1], dalpha
@@ -440,22 +447,34 @@ class ClnBlock(torch.autograd.Function):
         H = w1.shape[0]
         P = D.shape[-1]
         dev = x.device
+        sk = ctx.sinks
+        direct = all(t is not None for t in sk)       # FlatAdam: gradients go straight into the flat buffer
+        side = direct and _SIDE_ENABLED               # ... and the weight gradients to the second stream
         dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
-        dW2 = pw_wgrad(dout, n2, B, H, K)
-        dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K)
+        if side:
+            _wgrad_async(dout, n2, B, H, K, sk[8])
+            dW2 = None
+        else:
+            dW2 = pw_wgrad(dout, n2, B, H, K, out=sk[8] if direct else None)
+        dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K, sinks=(sk[6], sk[7], sk[5]) if direct else None)
         pc = torch.empty((P, M, H), dtype=F32, device=dev)
         dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
         _chk(dd, n1)
         lib.call("ctn_dw_bwd", _p(dd), 0, _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 0,
                  0, 0, 0, 0, 0, 0, 0, 0, 0, _p(pc), 0, _stream())
         dD = reduce_mid(pc, P, M, H).t().contiguous().view(H, 1, P)
-        dh1, dg1, db1, da1 = cln_bwd(dn1, h1, mean1, rstd1, g1, a1, K)
+        dh1, dg1, db1, da1 = cln_bwd(dn1, h1, mean1, rstd1, g1, a1, K, sinks=(sk[2], sk[3], sk[1]) if direct else None)
+        if side:
+            _wgrad_async(dh1, x, H, B, K, sk[0])
+            dW1 = None
         dx, _ = pw_gemm(w1, dh1, B, H, K, trans_w=True, residual=dout)
-        dW1 = pw_wgrad(dh1, x, H, B, K)
-        sk = ctx.sinks
-        return (dx, _emit(dW1.view(H, B, 1), sk[0]), _emit(da1, sk[1]), _emit(dg1.view(1, H, 1), sk[2]),
-                _emit(db1.view(1, H, 1), sk[3]), _emit(dD, sk[4]), _emit(da2, sk[5]), _emit(dg2.view(1, H, 1), sk[6]),
-                _emit(db2.view(1, H, 1), sk[7]), _emit(dW2.view(B, H, 1), sk[8]), None, None, None)
+        if not side:
+            dW1 = pw_wgrad(dh1, x, H, B, K, out=sk[0] if direct else None)
+        if direct:
+            sk[4].copy_(dD)
+            return (dx,) + (None,) * 12
+        return (dx, dW1.view(H, B, 1), da1, dg1.view(1, H, 1), db1.view(1, H, 1), dD, da2, dg2.view(1, H, 1),
+                db2.view(1, H, 1), dW2.view(B, H, 1), None, None, None)
 
 
 def bn_fwd(Y, alpha, weight, bias, running_mean, running_var, training, eps, momentum, K):
