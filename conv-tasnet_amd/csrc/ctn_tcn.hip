@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NT) void cln_bwd_dx_kernel(const float* __restrict_
 constexpr int CLN_NT = 1024, CLN_FR = 32;
 
 template <int FR, int CPT>
-__global__ __launch_bounds__(CLN_NT) void cln_fwd_reg_kernel(const float* __restrict__ Y, float* __restrict__ Out,
+__global__ __launch_bounds__(CLN_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void cln_fwd_reg_kernel(const float* __restrict__ Y, float* __restrict__ Out,
                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                              int M, int Ch, int K, int Kp, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ alpha_p) {
@@ -629,16 +629,16 @@ __global__ __launch_bounds__(CLN_NT) void cln_fwd_reg_kernel(const float* __rest
     }
 }
 
-template <int FR, int CPT>
-__global__ __launch_bounds__(CLN_NT) void cln_bwd_dx_reg_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+template <int FR, int CPT, int NTB>     // NTB threads per workgroup (512 or 1024)
+__global__ __launch_bounds__(NTB) void cln_bwd_dx_reg_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                                 float* __restrict__ dY, const float* __restrict__ mean_i,
                                                                 const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
                                                                 const float* __restrict__ gamma, const float* __restrict__ alpha_p,
                                                                 const float* __restrict__ add, const float* __restrict__ relu_ref,
                                                                 float* __restrict__ dalpha_part) {
-    constexpr int NG = CLN_NT / FR;
+    constexpr int NG = NTB / FR;
     __shared__ float sh[2][NG][FR];
-    __shared__ float red[CLN_NT / 64];
+    __shared__ float red[NTB / 64];
     const int fr = threadIdx.x % FR, g = threadIdx.x / FR;
     const int kb = (Kp + FR - 1) / FR;
     const int m = blockIdx.x / kb, k = (blockIdx.x % kb) * FR + fr;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(CLN_NT) void cln_bwd_dx_reg_kernel(const float* __r
         }
     }
     if (dalpha_part != nullptr) {
-        dal = block_sum<float, CLN_NT>(dal, red);
+        dal = block_sum<float, NTB>(dal, red);
         if (threadIdx.x == 0) dalpha_part[blockIdx.x] = dal;
     }
 }
@@ -938,13 +938,15 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     CTN_CHECK_LAUNCH("ctn_cln_bwd/params");
     const dim3 grid_r((unsigned)(M * ctn_cdiv(Kp, CLN_FR)));
     float* const dap = alpha ? dalpha_part : nullptr;
-#define CTN_CLN_BWD(CPT_) hipLaunchKernelGGL((cln_bwd_dx_reg_kernel<CLN_FR, CPT_>), grid_r, dim3(CLN_NT), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap)
-    const int cpt = ctn_cdiv(Ch, CLN_NT / CLN_FR);
-    if (cpt <= 2) CTN_CLN_BWD(2);
-    else if (cpt <= 4) CTN_CLN_BWD(4);
-    else if (cpt <= 8) CTN_CLN_BWD(8);
-    else if (cpt <= 16) CTN_CLN_BWD(16);
-    else {      // more than 512 channels: generic kernel; it fills only the first M*ceil(Kp/64) partials of the buffer
+    // <= 16 channels per thread keeps the kernel at ~100 VGPRs: 512-thread workgroups (two per CU) up to 256 channels,
+    // 1024-thread ones up to 512; wider layers take the generic kernel.
+#define CTN_CLN_BWD(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_dx_reg_kernel<CLN_FR, CPT_, NTB_>), grid_r, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap)
+    if (Ch <= 32) CTN_CLN_BWD(2, 512);
+    else if (Ch <= 64) CTN_CLN_BWD(4, 512);
+    else if (Ch <= 128) CTN_CLN_BWD(8, 512);
+    else if (Ch <= 256) CTN_CLN_BWD(16, 512);
+    else if (Ch <= 512) CTN_CLN_BWD(16, 1024);
+    else {      // generic kernel; it fills only the first M*ceil(Kp/64) partials of the buffer
         if (dap) hipMemsetAsync(dap, 0, sizeof(float) * (size_t)ctn_cln_bwd_blocks(M, Kp), st);
         hipLaunchKernelGGL(cln_bwd_dx_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st, dOut, Y, dY, mean, rstd, M,
                            Ch, K, Kp, gamma, alpha, add, relu_ref, dap);
