@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Training-step time of a paper-size model variant.  usage: python benchmarks/step_time.py [gLN|cLN|BN] [causal 0|1]"""
+"""Training-step time of a paper-size model variant.
+usage: python benchmarks/step_time.py [gLN|cLN|BN] [causal 0|1] [C] [L] [samples]   (C3 config of BASELINE: gLN 0 3 16 64000)"""
 import os
 import sys
 import time
@@ -12,11 +13,14 @@ from conv_tasnet_amd.train import SyntheticLoader  # noqa: E402
 
 norm = sys.argv[1] if len(sys.argv) > 1 else "gLN"
 causal = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 32000
 dev = "cuda:0"
 torch.manual_seed(0)
-m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2, norm_type=norm, causal=causal).to(dev)
+m = ctn.ConvTasNet(256, L, 256, 512, 3, 8, 4, C, norm_type=norm, causal=causal).to(dev)
 opt = FlatAdam(m.parameters(), lr=1e-3)
-mix, lens, src = next(iter(SyntheticLoader(1, 8)))
+mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=T, C=C, sample_rate=8000 * T // 32000)))
 mix, lens, src = mix.to(dev), lens.to(dev), src.to(dev)
 
 
@@ -37,4 +41,4 @@ for _ in range(n):
 t_issue = (time.perf_counter() - t0) / n
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print("%s causal=%d: %.2f ms/step, %.1f utt/s (host issue %.2f ms/step)" % (norm, causal, dt * 1e3, 8 / dt, t_issue * 1e3))
+print("%s causal=%d C=%d L=%d T=%d: %.2f ms/step, %.1f utt/s (host issue %.2f ms/step)" % (norm, causal, C, L, T, dt * 1e3, 8 / dt, t_issue * 1e3))
