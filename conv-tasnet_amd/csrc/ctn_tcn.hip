@@ -777,6 +777,28 @@ __global__ __launch_bounds__(NT) void dw_bwd_finalize_kernel(const float* __rest
     else db1[h] = s;
 }
 
+// Finish ctn_cln_bwd's partials in one launch: pc [2, M, Ch] -> dgamma[Ch], dbeta[Ch] (sum over m, thread per
+// channel); the last workgroup sums the nblk per-workgroup dalpha partials (fixed order).
+__global__ __launch_bounds__(NT) void cln_bwd_finalize_kernel(const float* __restrict__ pc, const float* __restrict__ dap,
+                                                              int M, int Ch, int nblk, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dalpha) {
+    __shared__ float red[NT / 64];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (dap == nullptr) return;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += NT) s += dap[i];
+        s = block_sum<float, NT>(s, red);
+        if (threadIdx.x == 0) dalpha[0] = s;
+        return;
+    }
+    const int o = blockIdx.x * NT + threadIdx.x;
+    if (o >= 2 * Ch) return;
+    const int f = o / Ch, c = o % Ch;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += pc[((size_t)f * M + m) * Ch + c];
+    (f == 0 ? dgamma : dbeta)[c] = s;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -953,6 +975,17 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     }
 #undef CTN_CLN_BWD
     CTN_CHECK_LAUNCH("ctn_cln_bwd/dx");
+    return CTN_OK;
+}
+
+int ctn_cln_bwd_finalize(const float* pc, const float* dalpha_part, int M, int Ch, int Kp, float* dgamma, float* dbeta,
+                         float* dalpha, void* stream) {
+    CTN_REQUIRE(pc && dgamma && dbeta && M > 0 && Ch > 0 && Kp > 0, "ctn_cln_bwd_finalize: bad arguments");
+    CTN_REQUIRE(!dalpha_part || dalpha, "ctn_cln_bwd_finalize: dalpha required with dalpha_part");
+    const unsigned nb = (unsigned)ctn_cdiv(2 * Ch, NT) + 1;
+    hipLaunchKernelGGL(cln_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, dalpha_part, M, Ch,
+                       ctn_cln_bwd_blocks(M, Kp), dgamma, dbeta, dalpha);
+    CTN_CHECK_LAUNCH("ctn_cln_bwd_finalize");
     return CTN_OK;
 }
 

@@ -276,14 +276,17 @@ def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None, sinks
     lib.call("ctn_cln_bwd", _p(dOut), _p(Y), _p(dY), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(alpha),
              _p(add), _p(relu_ref), _p(dap), _p(pc), _stream())
     if sinks is not None:
-        reduce_mid(pc[0], 1, M, Ch, out=sinks[0])
-        reduce_mid(pc[1], 1, M, Ch, out=sinks[1])
-        if dap is not None:
-            reduce_mid(dap, 1, dap.numel(), 1, out=sinks[2])
+        dg, db, da = sinks
+    else:
+        dg = torch.empty((Ch,), dtype=F32, device=Y.device)
+        db = torch.empty((Ch,), dtype=F32, device=Y.device)
+        da = None if dap is None else torch.empty((1,), dtype=F32, device=Y.device)
+    _chk(dg, db, da)
+    lib.call("ctn_cln_bwd_finalize", _p(pc), _p(dap), M, Ch, Kp, _p(dg), _p(db), _p(da if dap is not None else None),
+             _stream())
+    if sinks is not None:
         return dY, None, None, None
-    red = reduce_mid(pc, 2, M, Ch)
-    dalpha = None if dap is None else reduce_mid(dap, 1, dap.numel(), 1).view(1)
-    return dY, red[0], red[1], dalpha
+    return dY, dg, db, da
 
 
 def dw_fwd(Y, D, K, dilation, causal, pro=None, epi_alpha=None, ms_out=None):

@@ -156,6 +156,10 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
                 int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
                 const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream);
 int ctn_cln_bwd_blocks(int M, int Kp);
+/* One launch that finishes the partials above in fixed order: dgamma[Ch], dbeta[Ch] from pc, and dalpha[1] from
+ * dalpha_part [ctn_cln_bwd_blocks(M,Kp)] when that is non-NULL. */
+int ctn_cln_bwd_finalize(const float* pc, const float* dalpha_part, int M, int Ch, int Kp, float* dgamma, float* dbeta,
+                         float* dalpha, void* stream);
 
 /* ---- BatchNorm1d over (utterances, frames) per channel, optionally behind PReLU ------------------
  * replaces nn.BatchNorm1d as returned by chose_norm's else-branch, src/conv_tasnet.py:305-309, at its two uses
