@@ -164,6 +164,7 @@ _ws_cache = {}
 # FlatAdam.step()/the gradient all-reduce join the stream again (join_side_stream()).
 _side = {}
 _SIDE_ENABLED = os.environ.get("CTN_SIDE_STREAM", "1") != "0"
+_CLN_SIDE = os.environ.get("CTN_CLN_SIDE", "0") != "0"
 _SIDE_FIN = os.environ.get("CTN_SIDE_FIN", "0") != "0"   # finishing reductions on the side stream too: measured slower (464 vs 490)
 
 
@@ -470,7 +471,9 @@ class ClnBlock(torch.autograd.Function):
         dev = x.device
         sk = ctx.sinks
         direct = all(t is not None for t in sk)       # FlatAdam: gradients go straight into the flat buffer
-        side = direct and _SIDE_ENABLED               # ... and the weight gradients to the second stream
+        # The second stream does not pay here (22.7 vs 22.3 ms/step at paper size): the 1024-thread cLN kernels fill
+        # every wave slot of a CU, so the weight gradients only time-slice with them.  CTN_CLN_SIDE=1 turns it on.
+        side = direct and _SIDE_ENABLED and _CLN_SIDE
         dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
         if side:
             _wgrad_async(dout, n2, B, H, K, sk[8])
