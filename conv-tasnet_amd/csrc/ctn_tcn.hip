@@ -754,10 +754,20 @@ __global__ __launch_bounds__(NT) void reduce_mid_kernel(const float* __restrict_
 __global__ __launch_bounds__(NT) void dw_bwd_finalize_kernel(const float* __restrict__ pc, int P, int M, int H,
                                                              float* __restrict__ dD, float* __restrict__ dg2,
                                                              float* __restrict__ db2, float* __restrict__ dg1,
-                                                             float* __restrict__ db1, float* __restrict__ da2) {
+                                                             float* __restrict__ db1, float* __restrict__ da2,
+                                                             const float* __restrict__ da1_part, int n_da1,
+                                                             float* __restrict__ da1) {
     __shared__ float red[NT / 64];
     const size_t MH = (size_t)M * H;
-    if (blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.x == gridDim.x - 1) {                 // dalpha1 from gln_prelu_bwd's per-row partials (optional)
+        if (da1_part == nullptr) return;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_da1; i += NT) s += da1_part[i];
+        s = block_sum<float, NT>(s, red);
+        if (threadIdx.x == 0) da1[0] = s;
+        return;
+    }
+    if (blockIdx.x == gridDim.x - 2) {
         float s = 0.f;
         const float* src = pc + (size_t)(P + 4) * MH;
         for (size_t i = threadIdx.x; i < MH; i += NT) s += src[i];
@@ -901,12 +911,14 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
 }
 
 int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2,
-                        float* dgamma1, float* dbeta1, float* dalpha2, void* stream) {
+                        float* dgamma1, float* dbeta1, float* dalpha2, const float* dalpha1_part, int n_dalpha1,
+                        float* dalpha1, void* stream) {
     CTN_REQUIRE(pc && dD && dgamma2 && dbeta2 && dgamma1 && dbeta1 && dalpha2, "ctn_dw_bwd_finalize: null pointer");
     CTN_REQUIRE(P >= 1 && P <= MAXP && M > 0 && H > 0, "ctn_dw_bwd_finalize: bad sizes");
-    const unsigned nb = (unsigned)ctn_cdiv((P + 4) * H, NT) + 1;
+    CTN_REQUIRE(!dalpha1_part || (dalpha1 && n_dalpha1 > 0), "ctn_dw_bwd_finalize: incomplete dalpha1 arguments");
+    const unsigned nb = (unsigned)ctn_cdiv((P + 4) * H, NT) + 2;
     hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, P, M, H, dD, dgamma2,
-                       dbeta2, dgamma1, dbeta1, dalpha2);
+                       dbeta2, dgamma1, dbeta1, dalpha2, dalpha1_part, n_dalpha1, dalpha1);
     CTN_CHECK_LAUNCH("ctn_dw_bwd_finalize");
     return CTN_OK;
 }

@@ -411,20 +411,19 @@ class GlnBlock(torch.autograd.Function):
             dg2, db2, dg1, db1 = (torch.empty((1, H, 1), dtype=F32, device=dev) for _ in range(4))
             da2 = torch.empty((1,), dtype=F32, device=dev)
             da1 = torch.empty((1,), dtype=F32, device=dev)
-        # The fixed-order finishing reductions feed only parameter gradients.  CTN_SIDE_FIN=1 issues them with the first
-        # layer's weight gradient behind the event recorded after B4; the weight-gradient stream is the longer of the
-        # two, so that loses (464 vs 490 utt/s) and they stay on the chain by default.
-        def finish():
-            lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), _stream())
-            reduce_mid(da1p, 1, M * H, 1, out=da1)
-        side_fin = side and _SIDE_FIN
-        if not side_fin:
-            lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2), st)
         # -- gLN1 + PReLU1 backward, in place on dn1
         da1p = torch.empty((M * H,), dtype=F32, device=dev)
         lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), st)
+
+        # The fixed-order finishing reductions (one launch: depthwise-weight / gamma / beta / both alpha gradients) feed
+        # only parameter gradients.  CTN_SIDE_FIN=1 issues them with the first layer's weight gradient on the second
+        # stream; that stream is not the shorter one, so it loses (464 vs 490 utt/s) and they stay on the chain.
+        def finish():
+            lib.call("ctn_dw_bwd_finalize", _p(pc), P, M, H, _p(dD), _p(dg2), _p(db2), _p(dg1), _p(db1), _p(da2),
+                     _p(da1p), M * H, _p(da1), _stream())
+        side_fin = side and _SIDE_FIN
         if not side_fin:
-            reduce_mid(da1p, 1, M * H, 1, out=da1)
+            finish()
         # -- first 1x1
         if side:
             if side_fin:

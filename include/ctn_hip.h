@@ -135,9 +135,12 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
                const double* sums2_part, int sums2_nparts, float* pc, double* sums1_part, void* stream);
 int ctn_dw_bwd_rows(int P, int fused);
 /* Fixed-order finish of the fused backward's partials: pc [P+5,M,H] -> dD [H,P] (the depthwise weight's layout),
- * dgamma2, dbeta2, dgamma1, dbeta1 [H] and dalpha2 [1].  Destinations may be views into a flat gradient buffer. */
+ * dgamma2, dbeta2, dgamma1, dbeta1 [H] and dalpha2 [1]; when dalpha1_part (the [n_dalpha1] per-row partials of
+ * ctn_gln_prelu_bwd) is non-NULL the same launch also sums dalpha1 [1].  Destinations may be views into a flat
+ * gradient buffer. */
 int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2,
-                        float* dgamma1, float* dbeta1, float* dalpha2, void* stream);
+                        float* dgamma1, float* dbeta1, float* dalpha2, const float* dalpha1_part, int n_dalpha1,
+                        float* dalpha1, void* stream);
 
 /* dY = rstd*(gamma*dN - S1/n - xhat*S2/n) * prelu'(Y);  dalpha_part [M*H] = per-row sum over Y<0 of (..)*Y.
  * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN. */
