@@ -588,3 +588,75 @@ def test_bn_trains_with_flat_adam_and_standalone_module():
     want = torch.nn.functional.batch_norm(x.cpu(), bnm.running_mean.cpu(), bnm.running_var.cpu(), bnm.weight.detach().cpu(),
                                           bnm.bias.detach().cpu(), False, 0.1, 1e-5)
     assert rel_err(bnm(x), want) < 1e-5
+
+
+# ----------------------------------------------------------------------------- plan / width variants of the kernels
+@pytest.mark.parametrize("tile,blocks", [(64, 256), (12864, 512), (128, 512), (64, 1024)])
+def test_pw_wgrad_every_plan(tile, blocks):
+    """The split-K weight gradient under every tile / workgroup plan ctn_tune_wgrad offers (ragged R, Cn, K)."""
+    M, R, Cn, K = 3, 200, 132, 1301
+    Kp = ops.padded_frames(K)
+    dO = pad(torch.randn(M, R, K, generator=g(11)), Kp)
+    X = pad(torch.randn(M, Cn, K, generator=g(12)), Kp)
+    ref = torch.einsum("mrk,mck->rc", dO.double(), X.double())
+    gam, bet = torch.randn(1, Cn, 1, generator=g(13)), torch.randn(1, Cn, 1, generator=g(14))
+    al = torch.tensor([0.2])
+    ms = torch.tensor([[0.1, 1.3], [-0.2, 0.7], [0.05, 1.1]])
+    xn = gam * ((torch.where(X >= 0, X, al * X) - ms[:, 0].view(-1, 1, 1)) * ms[:, 1].view(-1, 1, 1)) + bet
+    xn[..., K:] = 0
+    ref_pro = torch.einsum("mrk,mck->rc", dO.double(), xn.double())
+    try:
+        ctn.lib.call("ctn_tune_wgrad", tile, blocks)
+        out = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K)
+        out_pro = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K, pro=(gam.to(DEV), bet.to(DEV), al.to(DEV), ms.to(DEV)))
+    finally:
+        ctn.lib.call("ctn_tune_wgrad", 0, 512)
+    assert rel_err(out, ref) < 5e-6
+    assert rel_err(out_pro, ref_pro) < 5e-6
+
+
+@pytest.mark.parametrize("Ch,K", [(8, 50), (40, 333), (300, 95), (520, 70), (1100, 40)])
+@pytest.mark.parametrize("with_prelu", [True, False])
+def test_cln_kernels_every_width(Ch, K, with_prelu):
+    """Channel-wise LayerNorm (+PReLU) forward / backward across the register-resident configurations (2..32 channels
+    per thread, 512- and 1024-thread workgroups) and the generic fallback for very wide layers, against fp64 torch."""
+    M = 2
+    Kp = ops.padded_frames(K)
+    y = (torch.randn(M, Ch, K, generator=g(21)) * 1.5 + 0.2).double().requires_grad_(True)
+    gam = (1 + 0.3 * torch.randn(1, Ch, 1, generator=g(22))).double().requires_grad_(True)
+    bet = (0.2 * torch.randn(1, Ch, 1, generator=g(23))).double().requires_grad_(True)
+    al = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    dout = torch.randn(M, Ch, K, generator=g(24)).double()
+    p = torch.where(y >= 0, y, al * y) if with_prelu else y
+    mu = p.mean(1, keepdim=True)
+    var = ((p - mu) ** 2).mean(1, keepdim=True)
+    ref = gam * (p - mu) / torch.sqrt(var + 1e-8) + bet
+    ref.backward(dout)
+    a_d = al.detach().float().to(DEV) if with_prelu else None
+    yd = pad(y.detach().float(), Kp).to(DEV)
+    out, mean, rstd = ops.cln_fwd(yd, gam.detach().float().to(DEV), bet.detach().float().to(DEV), a_d, K)
+    assert rel_err(out[..., :K], ref) < 2e-5
+    if Kp > K:
+        assert float(out[..., K:].abs().max()) == 0.0
+    dy, dg, db, da = ops.cln_bwd(pad(dout.float(), Kp).to(DEV), yd, mean, rstd, gam.detach().float().to(DEV), a_d, K)
+    assert rel_err(dy[..., :K], y.grad) < 5e-5
+    assert rel_err(dg, gam.grad.view(-1)) < 5e-5 and rel_err(db, bet.grad.view(-1)) < 5e-5
+    if with_prelu:
+        assert rel_err(da, al.grad) < 5e-5
+
+
+def test_stream_order_entry_point():
+    """ctn_stream_order: work enqueued on `to` after the call sees everything enqueued on `from` before it."""
+    s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    x = torch.zeros(1 << 24, device=DEV)
+    torch.cuda.synchronize()
+    for it in range(5):
+        with torch.cuda.stream(s1):
+            for _ in range(20):
+                x.add_(1.0)                      # a long queue on s1
+        ctn.lib.call("ctn_stream_order", s1.cuda_stream, s2.cuda_stream)
+        with torch.cuda.stream(s2):
+            y = x.clone()                        # must observe all 20 increments of this round
+        s2.synchronize()
+        assert float(y.min()) == float(y.max()) == 20.0 * (it + 1)
+        ctn.lib.call("ctn_stream_order", s2.cuda_stream, s1.cuda_stream)
