@@ -7,7 +7,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libctn_hip.so")
-SOURCES = ["ctn_api.hip", "ctn_gemm.hip", "ctn_tcn.hip", "ctn_bn.hip", "ctn_codec.hip", "ctn_loss.hip", "ctn_optim.hip"]
+SOURCES = ["ctn_api.hip", "ctn_gemm.hip", "ctn_tcn.hip", "ctn_bn.hip", "ctn_codec.hip", "ctn_loss.hip", "ctn_optim.hip",
+           "ctn_block.hip"]
+# opt-in experiment (split-bf16 GEMMs, include/ctn_hip_experimental.h): CTN_BUILD_X6=1
+if os.environ.get("CTN_BUILD_X6") == "1":
+    SOURCES.append(os.path.join("experimental", "ctn_gemm_x6.hip"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("CTN_EXTRA_HIPCC_FLAGS", "").split()
 
 
@@ -27,12 +31,12 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     """Compile every .hip source for gfx950 and link libctn_hip.so next to this file."""
-    hdrs = [os.path.join(CSRC, "ctn_common.h")]
+    hdrs = [os.path.join(CSRC, "ctn_common.h"), os.path.join(CSRC, "ctn_gemm_common.h")]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, "build", os.path.basename(s).replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])

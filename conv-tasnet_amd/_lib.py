@@ -8,7 +8,11 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ctn_hip.h")
-LIB_PATH = os.path.join(_HERE, "libctn_hip.so")
+HEADER_EXPERIMENTAL = os.path.join(os.path.dirname(_HERE), "include", "ctn_hip_experimental.h")
+# CTN_LIB_PATH: an alternative build of the same ABI (benchmarks/gemm_lab.py compares experiment builds)
+LIB_PATH = os.environ.get("CTN_LIB_PATH") or os.path.join(_HERE, "libctn_hip.so")
+# CTN_EXPERIMENTAL=1 also binds include/ctn_hip_experimental.h (needs a library built with CTN_BUILD_X6=1)
+EXPERIMENTAL = os.environ.get("CTN_EXPERIMENTAL") == "1"
 
 _SCALARS = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float,
             "size_t": ctypes.c_size_t, "double": ctypes.c_double}
@@ -49,6 +53,8 @@ class _Lib:
     def __init__(self):
         self._dll = None
         self.protos = parse_header()
+        if EXPERIMENTAL:
+            self.protos.update(parse_header(HEADER_EXPERIMENTAL))
 
     def load(self):
         if self._dll is None:

@@ -193,9 +193,16 @@ class TemporalConvNet(nn.Module):
         return w, x, K
 
     def blocks(self, x, K):
-        for rep in self.network[2]:
-            for blk in rep:
-                x = blk.fused(x, K)
+        blks = [blk for rep in self.network[2] for blk in rep]
+        if ops.composite_enabled() and blks and all(b.norm_type == "gLN" for b in blks):
+            # the whole stack behind one C call per direction (ctn_tcn_gln_fwd / _bwd); bitwise the per-block path
+            params = [p for b in blks for p in b.fused_params()]
+            dil = [b.dilation for b in blks]
+            if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+                return ops.TcnGln.apply(x, K, dil, blks[0].causal, *params)
+            return ops.tcn_gln_infer(x.contiguous(), K, dil, blks[0].causal, params)
+        for blk in blks:
+            x = blk.fused(x, K)
         return x
 
     def forward(self, mixture_w):
@@ -267,6 +274,13 @@ class TemporalBlock(nn.Module):
                                         norm_type, causal)
         self.net = nn.Sequential(conv1x1, prelu, norm, dsconv)
         self.dilation, self.causal, self.norm_type = dilation, bool(causal), norm_type
+
+    def fused_params(self):
+        """The 9 parameter tensors of a gLN / cLN block in the C ABI's order (include/ctn_hip.h, ctn_tcn_gln_fwd)."""
+        ds = self.net[3]
+        norm1, norm2 = self.net[2], ds.norm()
+        return (self.net[0].weight, self.net[1].weight, norm1.gamma, norm1.beta, ds.net[0].weight, ds.prelu().weight,
+                norm2.gamma, norm2.beta, ds.pointwise().weight)
 
     def fused(self, x, K):
         ds = self.net[3]

@@ -1,0 +1,169 @@
+// Composite entry points: a whole stack of gLN TemporalBlocks behind ONE call of the C ABI.
+//
+// The reference runs `temporal_conv_net = nn.Sequential(*repeats)` (src/conv_tasnet.py:176-186): X*R TemporalBlocks
+// (:218-278), each  x + pw2(gLN(prelu(dw(gLN(prelu(pw1(x)))))))  -- one Python call per module.  Here the host issues
+// every launch of the stack (3 per block forward, 6 + 2 weight-gradient launches per block backward) from C++, so the
+// Python side of a training step makes ~50 calls instead of ~450 and the GPU queues never run dry (round 1: the host
+// needed 12.7 ms to enqueue a 15.8 ms step).  The per-kernel entry points stay the unit-tested surface; these
+// composites call exactly those, in the order ops.GlnBlock does, so results are bitwise identical.
+//
+// Streams: the two weight-gradient GEMMs of a block feed only the optimiser; with side_stream != NULL they are issued
+// there behind a device-scope event (ctn_stream_order) and overlap the HBM-bound kernels of the backward chain.  The
+// call ends by ordering `stream` after `side_stream`, so every gradient is complete in stream order when it returns.
+#include "ctn_common.h"
+#include "../../include/ctn_hip.h"
+
+namespace {
+
+enum { P_W1 = 0, P_A1, P_G1, P_B1, P_D, P_A2, P_G2, P_B2, P_W2, NPARAM };
+
+inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
+struct FwdWs {
+    size_t st1, st2, total;
+    int np1;
+};
+FwdWs fwd_ws(int M, int B, int H, int Kp) {
+    (void)B;
+    FwdWs w;
+    w.np1 = ctn_pw_stats_parts(M, H, Kp);
+    w.st1 = 0;
+    w.st2 = align256((size_t)M * w.np1 * 2 * sizeof(double));
+    w.total = w.st2 + align256((size_t)M * H * 2 * sizeof(double));
+    return w;
+}
+
+struct BwdWs {
+    size_t dn2, s2p, s1p, pc, da1p, slab, total;
+    size_t slab_bytes;
+    int np2;
+};
+BwdWs bwd_ws(int M, int B, int H, int Kp, int P) {
+    BwdWs w;
+    w.np2 = ctn_pw_stats_parts(M, H, Kp);
+    size_t o = 0;
+    w.dn2 = o; o += align256((size_t)M * H * Kp * sizeof(float));
+    w.s2p = o; o += align256((size_t)M * w.np2 * 2 * sizeof(double));
+    w.s1p = o; o += align256((size_t)M * H * 2 * sizeof(double));
+    w.pc = o; o += align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
+    w.da1p = o; o += align256((size_t)M * H * sizeof(float));
+    const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
+    w.slab_bytes = s1 > s2 ? s1 : s2;
+    w.slab = o; o += align256(w.slab_bytes);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp) { return fwd_ws(M, B, H, Kp).total; }
+size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P) { return bwd_ws(M, B, H, Kp, P).total; }
+
+int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
+                    float* xs, float* h1s, float* ds, float* ms, int save,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && workspace, "ctn_tcn_gln_fwd: null pointer");
+    CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_fwd: bad sizes");
+    const FwdWs w = fwd_ws(M, B, H, Kp);
+    if (workspace_bytes < w.total) {
+        ctn_set_error("ctn_tcn_gln_fwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+        return CTN_ERR_WORKSPACE;
+    }
+    double* const st1 = (double*)((char*)workspace + w.st1);
+    double* const st2 = (double*)((char*)workspace + w.st2);
+    const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
+    const float* x = x0;
+    for (int i = 0; i < nblocks; ++i) {
+        const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
+        // save = 0 (inference): one h1 / d slot and two ping-pong x slots; save = 1: a slot per block for the backward pass
+        float* const h1 = h1s + (save ? (size_t)i * hsz : 0);
+        float* const d = ds + (save ? (size_t)i * hsz : 0);
+        float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
+        float* const ms1 = ms + ((size_t)(save ? i : 0) * 2 + 0) * M * 2;
+        float* const ms2 = ms + ((size_t)(save ? i : 0) * 2 + 1) * M * 2;
+        int rc = ctn_pw_gemm(p[P_W1], x, h1, M, H, B, K, Kp, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             p[P_A1], st1, 0, stream);
+        if (rc) return rc;
+        rc = ctn_dw_fwd(h1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, st1, w.np1, p[P_G1], p[P_B1], p[P_A1], ms1,
+                        p[P_A2], st2, stream);
+        if (rc) return rc;
+        rc = ctn_pw_gemm(p[P_W2], d, out, M, B, H, K, Kp, 0, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
+                         stream);
+        if (rc) return rc;
+        x = out;
+    }
+    return CTN_OK;
+}
+
+int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
+                    const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
+                    const float* dout, float* dxs, float* dn1s,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
+    CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && dout && dxs && dn1s && workspace,
+                "ctn_tcn_gln_bwd: null pointer");
+    CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_bwd: bad sizes");
+    const BwdWs w = bwd_ws(M, B, H, Kp, P);
+    if (workspace_bytes < w.total) {
+        ctn_set_error("ctn_tcn_gln_bwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+        return CTN_ERR_WORKSPACE;
+    }
+    char* const ws = (char*)workspace;
+    float* const dn2 = (float*)(ws + w.dn2);
+    double* const s2p = (double*)(ws + w.s2p);
+    double* const s1p = (double*)(ws + w.s1p);
+    float* const pc = (float*)(ws + w.pc);
+    float* const da1p = (float*)(ws + w.da1p);
+    void* const slab = ws + w.slab;
+    const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
+    void* const wst = side_stream ? side_stream : stream;       // where the weight gradients go
+    int rc;
+    for (int i = nblocks - 1; i >= 0; --i) {
+        const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+        float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
+        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j] && g[j], "ctn_tcn_gln_bwd: block %d parameter / gradient %d is null", i, j);
+        const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
+        const float* const h1 = h1s + (size_t)i * hsz;
+        const float* const d = ds + (size_t)i * hsz;
+        const float* const ms1 = ms + ((size_t)i * 2 + 0) * M * 2;
+        const float* const ms2 = ms + ((size_t)i * 2 + 1) * M * 2;
+        const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;   // gradient of this block's output
+        float* const dx = dxs + (size_t)i * xsz;
+        float* const dn1 = dn1s + (size_t)i * hsz;      // a slot per block: the side stream still reads it while the chain moves on
+        // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
+        rc = ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
+        if (rc) return rc;
+        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        rc = ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst);
+        if (rc) return rc;
+        // gLN2 <- PReLU2 <- depthwise <- gLN1 output in one pass, then gLN1 + PReLU1 backward in place
+        rc = ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
+                        p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream);
+        if (rc) return rc;
+        rc = ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream);
+        if (rc) return rc;
+        rc = ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, M * H, g[P_A1], stream);
+        if (rc) return rc;
+        // first 1x1
+        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        if (side_stream) {
+            rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
+            if (rc) return rc;
+        }
+        rc = ctn_pw_gemm(p[P_W1], dn1, dx, M, B, H, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr,
+                         nullptr, 0, stream);
+        if (rc) return rc;
+        if (!side_stream) {
+            rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
+            if (rc) return rc;
+        }
+    }
+    if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;
+    return CTN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// Shared device / host pieces of the 1x1-convolution GEMM translation units (fp32-MFMA product kernels in
+// ctn_gemm.hip; the opt-in split-bf16 experiment in experimental/ctn_gemm_x6.hip).  gfx950 only.
+#pragma once
+#include "ctn_common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
+
+enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4 };
+
+// Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
+// in 32x32 MFMA tiles.  Smaller tiles trade operand reuse (plentiful: one fp32 MFMA = 64 cycles for one
+// A and one B dword per lane) for finer load balance over the 256 CUs.
+template <int BM_, int BN_, int WGM_, int WGN_, int BK_ = 16>
+struct Tile {
+    static constexpr int TM = BM_, TN = BN_, WGM = WGM_, WGN = WGN_, TK = BK_;
+    static constexpr int WM = BM_ / WGM_, WN = BN_ / WGN_;
+    static constexpr int MT = WM / 32, NTL = WN / 32;
+    static constexpr int LDA = BM_ + 4, LDB = BN_ + 4, LDS_ST = WN + 4;
+    static constexpr int MAIN_FLOATS = 2 * BK_ * (LDA + LDB);
+    static constexpr int NW = WGM_ * WGN_, NTH = 64 * NW;          // waves / threads per workgroup
+    static constexpr int STAGE_FLOATS = NW * 32 * LDS_ST;
+    static constexpr int SMEM_FLOATS = MAIN_FLOATS > STAGE_FLOATS ? MAIN_FLOATS : STAGE_FLOATS;
+    static_assert((NW == 4 || NW == 8) && WM % 32 == 0 && WN % 32 == 0, "4 or 8 waves of 32x32 MFMA tiles");
+};
+using T128x128 = Tile<128, 128, 2, 2>;
+using T128x64 = Tile<128, 64, 2, 2>;
+using T64x128 = Tile<64, 128, 2, 2>;
+using T64x64 = Tile<64, 64, 2, 2>;
+using T128x64w = Tile<128, 64, 4, 1>;
+using T64x64k32 = Tile<64, 64, 2, 2, 32>;
+using T128x64k32 = Tile<128, 64, 2, 2, 32>;
+using T128x128k32 = Tile<128, 128, 2, 2, 32>;
+using T128x128w8 = Tile<128, 128, 2, 4>;      // 8 waves, each 64x32 (split-bf16 kernels only)
+using T128x64w8 = Tile<128, 64, 4, 2>;        // 8 waves, each 32x32
+using T128x64w8k32 = Tile<128, 64, 4, 2, 32>; // the fp32 kernel needs a 32-deep k-tile to give 512 threads a float4 each
+
+struct PwArgs {
+    const float* W;      // TRANS_W=0: [R, Cn]   TRANS_W=1: [Cn, R]
+    const float* X;      // [M, Cn, Kp]
+    float* Out;          // [M, R, Kp]
+    int M, R, Cn, K, Kp;
+    int tiles_r, tiles_c;
+    // operand prologue: x' = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i], 0 for k>=K
+    const double* pro_part; int pro_nparts;
+    const float* pro_gamma; const float* pro_beta; const float* pro_alpha;
+    float* pro_ms_out;   // [M,2] (mean, rstd) for the backward pass, optional
+    // epilogues
+    const float* residual;                         // EPI_RESIDUAL: [M,R,Kp]
+    const float* epi_alpha; double* epi_part;      // EPI_PRELU_STATS: [M, tiles_r*tiles_c, 2]
+    const float* bwd_y; const float* bwd_gamma; const float* bwd_alpha;
+    const float* bwd_ms; double* bwd_part;         // EPI_GLN_BWD
+    // split-bf16 pipeline: optional per-(m,row) bias added for k < K, and the result also emitted as three bf16 planes
+    const float* row_bias;                         // [M, R] or NULL
+    void* out_planes; size_t out_plane_stride;     // [3][M,R,Kp] bf16 or NULL; stride between planes in elements
+    int store_f32;                                 // 0: skip the fp32 store (planes only)
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Buffer (SRSRC) loads: 32-bit per-lane byte offset + scalar offset, and the hardware range check returns 0 for any
+// 16-byte access that ends past `bytes` -- no per-load predicates, zero fills or 64-bit address arithmetic in the
+// main loops (VALU instructions do not overlap the MFMAs of the other waves on a SIMD, so every one of them is
+// paid in full; see profiles/README.md).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    // (bit_cast the whole vector: clang lowers __builtin_bit_cast(float, v[i]) of a vector ELEMENT to element 0)
+    const f32x4v f = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  The row tiles that re-read the same
+// activation columns are consecutive tile indices, so give each XCD a contiguous range of tile indices: its private
+// L2 then serves the re-reads instead of the fabric.  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// Operand prologue: gLN(prelu(x)) = gamma*((prelu(x)-mean)*rstd)+beta, folded to one select + one FMA per element:
+//   gs = gamma*rstd, cc = beta - gs*mean  ->  x' = x * (x >= 0 ? gs : gs*alpha) + cc ;  0 for frames k >= K.
+__device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, float b, float alpha, float mean, float rstd) {
+    const float gs = g * rstd, cc = b - gs * mean, gn = gs * alpha;
+    v.x = fmaf(v.x, v.x >= 0.f ? gs : gn, cc);
+    v.y = fmaf(v.y, v.y >= 0.f ? gs : gn, cc);
+    v.z = fmaf(v.z, v.z >= 0.f ? gs : gn, cc);
+    v.w = fmaf(v.w, v.w >= 0.f ? gs : gn, cc);
+    if (k + 3 >= K) {                       // only the last column tile of an utterance
+        if (k + 0 >= K) v.x = 0.f;
+        if (k + 1 >= K) v.y = 0.f;
+        if (k + 2 >= K) v.z = 0.f;
+        if (k + 3 >= K) v.w = 0.f;
+    }
+    return v;
+}
+
+// exact 3-way bf16 split of an fp32 value: v = a + b + c, 8 significand bits each
+struct Bf3 { __bf16 a, b, c; };
+__device__ __forceinline__ Bf3 split3(float v) {
+    Bf3 r;
+    r.a = (__bf16)v;
+    const float r1 = v - (float)r.a;
+    r.b = (__bf16)r1;
+    r.c = (__bf16)(r1 - (float)r.b);
+    return r;
+}
+// four consecutive fp32 -> the three bf16x4 pieces
+__device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2, bf16x4& q3) {
+    const Bf3 s0 = split3(v.x), s1 = split3(v.y), s2 = split3(v.z), s3 = split3(v.w);
+    q1 = bf16x4{s0.a, s1.a, s2.a, s3.a};
+    q2 = bf16x4{s0.b, s1.b, s2.b, s3.b};
+    q3 = bf16x4{s0.c, s1.c, s2.c, s3.c};
+}
+
+
+// ---- shared epilogue (fp32-MFMA and split-bf16 kernels: the 32x32 C/D register map is dtype-independent) ----
+// Each wave transposes its accumulators through a private LDS patch (32 rows at a time) so that global traffic
+// is 16 bytes per lane along frames instead of 64 dword accesses; residual / ReLU / PReLU-statistics / gLN-backward
+// sums are applied on the float4s.  C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+// NTHB: threads of the workgroup (>= TL::NTH); waves beyond TL::NW pass active = false, hold no accumulators and only
+// take part in the block-wide sums.  EXTRAS: per-row bias and bf16-plane output of the pre-split ("p6") kernels.
+// Global traffic goes through buffer descriptors of this utterance's [R, Kp] matrices: rows >= R are dropped /
+// read as 0 by the hardware range check (their accumulators are exact zeros, so the statistics need no row
+// predicate either); only a tile that overhangs Kp -- a uniform condition -- masks its columns per lane.
+template <typename TL, int EPI, int NTHB = TL::NTH, bool EXTRAS = false>
+__device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL::MT][TL::NTL], float* smem, double* red,
+                                              int m, int rt, int ct, bool active = true) {
+    constexpr int MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, TM = TL::TM, TN = TL::TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WGN, wn = wave % TL::WGN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int r0 = rt * TM, c0 = ct * TN;
+    float e_alpha = 0.f, b_mean = 0.f, b_rstd = 1.f;
+    if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
+    if constexpr (EPI == EPI_GLN_BWD) {
+        e_alpha = a.bwd_alpha[0];
+        b_mean = a.bwd_ms[2 * m];
+        b_rstd = a.bwd_ms[2 * m + 1];
+    }
+    constexpr int LST = TL::LDS_ST;
+    constexpr int C4 = WN / 4;              // lanes per staged row
+    constexpr int RPP = 64 / C4;            // rows per pass
+    float* const stage = smem + wave * 32 * LST;
+    float s1 = 0.f, s2 = 0.f;
+    const size_t mbase = (size_t)m * a.R * a.Kp;
+    const unsigned mat_bytes = (unsigned)a.R * (unsigned)a.Kp * 4u;
+    const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, a.store_f32 ? mat_bytes : 0u);
+    __amdgpu_buffer_rsrc_t rsAux = rsOut, rsGam = rsOut;
+    if constexpr (EPI == EPI_RESIDUAL) rsAux = make_rsrc(a.residual + mbase, mat_bytes);
+    if constexpr (EPI == EPI_GLN_BWD) {
+        rsAux = make_rsrc(a.bwd_y + mbase, mat_bytes);
+        rsGam = make_rsrc(a.bwd_gamma, (unsigned)a.R * 4u);
+    }
+    const bool ragged = c0 + TN > a.Kp;     // uniform
+    const int rl0 = lane / C4, cl = (lane % C4) * 4;
+    const int kcol = c0 + wn * WN + cl;
+    const int vo0 = ((r0 + wm * WM + rl0) * a.Kp + kcol) * 4;
+    if (active)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[((e & 3) + 8 * (e >> 2) + 4 * lhi) * LST + nt * 32 + l31] = acc[mt][nt][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 32 / RPP; ++p) {
+            const int rl = p * RPP + rl0;
+            const int so = (mt * 32 + p * RPP) * a.Kp * 4;                  // scalar byte offset of this pass
+            float4 v = *reinterpret_cast<const float4*>(stage + rl * LST + cl);
+            if (!ragged || kcol < a.Kp) {
+                if constexpr (EPI == EPI_RESIDUAL) {
+                    const float4 q = buf_ld4(rsAux, vo0, so);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                if constexpr (EPI == EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if constexpr (EPI == EPI_PRELU_STATS) {
+                    const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
+                    const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
+                    s1 += (p0 + p1) + (p2 + p3);
+                    s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+                }
+                if constexpr (EPI == EPI_GLN_BWD) {
+                    const float4 y = buf_ld4(rsAux, vo0, so);
+                    const float g = buf_ld1(rsGam, (r0 + wm * WM + rl0) * 4, (mt * 32 + p * RPP) * 4);
+                    const float t0 = g * v.x, t1 = g * v.y, t2 = g * v.z, t3 = g * v.w;
+                    const float x0 = (prelu_f(y.x, e_alpha) - b_mean) * b_rstd, x1 = (prelu_f(y.y, e_alpha) - b_mean) * b_rstd;
+                    const float x2 = (prelu_f(y.z, e_alpha) - b_mean) * b_rstd, x3 = (prelu_f(y.w, e_alpha) - b_mean) * b_rstd;
+                    s1 += (t0 + t1) + (t2 + t3);
+                    s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
+                }
+                if constexpr (EXTRAS) {
+                    const int r = r0 + wm * WM + mt * 32 + rl;
+                    if (a.row_bias != nullptr && r < a.R) {
+                        const float bia = a.row_bias[(size_t)m * a.R + r];
+                        v.x += (kcol + 0 < a.K) ? bia : 0.f; v.y += (kcol + 1 < a.K) ? bia : 0.f;
+                        v.z += (kcol + 2 < a.K) ? bia : 0.f; v.w += (kcol + 3 < a.K) ? bia : 0.f;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, f32x4v{v.x, v.y, v.z, v.w}), rsOut, vo0, so, 0);
+                if constexpr (EXTRAS) {
+                    const int r = r0 + wm * WM + mt * 32 + rl;
+                    if (a.out_planes != nullptr && r < a.R) {
+                        bf16x4 q1, q2, q3;
+                        split3x4(v, q1, q2, q3);
+                        __bf16* P = reinterpret_cast<__bf16*>(a.out_planes) + mbase + (size_t)r * a.Kp + kcol;
+                        *reinterpret_cast<bf16x4*>(P) = q1;
+                        *reinterpret_cast<bf16x4*>(P + a.out_plane_stride) = q2;
+                        *reinterpret_cast<bf16x4*>(P + 2 * a.out_plane_stride) = q3;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
+        const double d1 = block_sum<double, NTHB>((double)s1, red);
+        const double d2 = block_sum<double, NTHB>((double)s2, red);
+        if (tid == 0) {
+            double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
+                          ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 2;
+            dst[0] = d1;
+            dst[1] = d2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dW[r,c] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]); split over (m, k-chunks)
+// into fp32 slabs that a second kernel sums in a fixed order (bitwise reproducible).
+// ---------------------------------------------------------------------------
+constexpr int WK = 16, LDW = 17;
+
+struct WgArgs {
+    const float* dOut;   // [M, R, Kp]
+    const float* X;      // [M, Cn, Kp]
+    float* slab;         // [nsplit, R, Cn]
+    int M, R, Cn, K, Kp;
+    int tiles_r, tiles_c, chunk, chunks_per_m;
+    const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
+};
+
+
+__global__ __launch_bounds__(NT) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long long n,
+                                                         float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + i];
+    out[i] = s;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_common(const char* fn, const float* W, const float* X, const float* Out, int M, int R, int Cn, int K, int Kp) {
+    CTN_REQUIRE(W && X && Out, "%s: null pointer", fn);
+    CTN_REQUIRE(M > 0 && R > 0 && Cn > 0 && K > 0 && Kp >= K, "%s: bad sizes M=%d R=%d Cn=%d K=%d Kp=%d", fn, M, R, Cn, K, Kp);
+    CTN_REQUIRE(Kp % 4 == 0 && R % 4 == 0 && Cn % 4 == 0, "%s: Kp, rows and contraction must be multiples of 4 (Kp=%d R=%d Cn=%d)", fn, Kp, R, Cn);
+    CTN_REQUIRE(aligned16(W) && aligned16(X) && aligned16(Out), "%s: pointers must be 16-byte aligned", fn);
+    CTN_REQUIRE((long long)R * Cn * 4 < (1ll << 31) && (long long)(Cn > R ? Cn : R) * Kp * 4 < (1ll << 31),
+                "%s: one weight matrix / one utterance's activations must stay below 2 GiB (32-bit buffer offsets)", fn);
+    return CTN_OK;
+}
+
+
+}  // namespace
+
+// ---- tile selection (shared by the fp32 and the experimental launchers; ctn_tune_pw_tile sets the override) ----
+// id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32,
+//     8 / 9 = 128x128 / 128x64 with 8 waves (512 threads; the fp32 128x64 variant uses BK = 32)
+//     10 = 128x128 wave-specialised (split-bf16 forward/dgrad kernels only; fp32 kernels map it to 0)
+extern int g_ctn_tile_override;   // -2: not read yet, -1: heuristic (defined in ctn_gemm.hip)
+
+static void tile_dims(int id, int* tm, int* tn) {
+    static const int d[11][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}, {128, 128}};
+    *tm = d[id][0];
+    *tn = d[id][1];
+}
+
+static int pick_tile(int M, int R, int Kp) {
+    if (g_ctn_tile_override == -2) {
+        const char* e = getenv("CTN_PW_TILE");
+        g_ctn_tile_override = (e && *e) ? atoi(e) : -1;
+        if (g_ctn_tile_override < -1 || g_ctn_tile_override > 10) g_ctn_tile_override = -1;
+    }
+    if (g_ctn_tile_override >= 0) return g_ctn_tile_override;
+    // Measured on MI355X (benchmarks/gemm_sweep.py, paper shapes): 64x64 tiles win every variant -- 3200 / 1600
+    // workgroups balance over the 256 CUs far better than 800 / 400 tiles of 128x128, and one fp32 MFMA (64 cycles)
+    // needs so little operand bandwidth that the smaller tile's lower reuse costs nothing.
+    (void)M; (void)R; (void)Kp;
+    const int best_id = 3;
+    return best_id;
+}

@@ -25,16 +25,24 @@ F32 = torch.float32
 F64 = torch.float64
 BF16 = torch.bfloat16
 
-# GEMM arithmetic: "fp32" = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains); "x6" = split-bf16 emulation on the
-# bf16 matrix cores (three bf16 pieces per operand, six MFMAs, fp32-level accuracy at 2.7x the fp32-MFMA rate).
-_GEMM_MODE = os.environ.get("CTN_GEMM_MODE", "fp32")
+# GEMM arithmetic: "fp32" = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains), the product path.  "x6" = the split-bf16
+# experiment (include/ctn_hip_experimental.h): only with a CTN_BUILD_X6=1 library and CTN_EXPERIMENTAL=1.
+_GEMM_MODE = "fp32"
 
 
 def set_gemm_mode(mode):
     global _GEMM_MODE
     if mode not in ("fp32", "x6"):
         raise ValueError("gemm mode must be 'fp32' or 'x6'")
+    if mode == "x6":
+        from ._lib import EXPERIMENTAL
+        if not EXPERIMENTAL:
+            raise CtnError("gemm mode 'x6' is an experiment: build with CTN_BUILD_X6=1 and run with CTN_EXPERIMENTAL=1")
     _GEMM_MODE = mode
+
+
+if os.environ.get("CTN_GEMM_MODE", "fp32") != "fp32":
+    set_gemm_mode(os.environ["CTN_GEMM_MODE"])
 
 
 def gemm_mode():
@@ -436,6 +444,109 @@ class GlnBlock(torch.autograd.Function):
         if direct:
             return (dx,) + (None,) * 12
         return (dx, dW1.view(H, B, 1), da1, dg1, db1, dD, da2, dg2, db2, dW2.view(B, H, 1), None, None, None)
+
+
+# ---------------------------------------------------------------------------------------
+# The whole stack of gLN TemporalBlocks as ONE autograd node over the composite entry points
+# (ctn_tcn_gln_fwd / ctn_tcn_gln_bwd): the host side of 32 blocks is two C calls instead of ~400.
+# ---------------------------------------------------------------------------------------
+import ctypes  # noqa: E402
+
+_COMPOSITE = os.environ.get("CTN_COMPOSITE", "1") != "0"
+NPARAM = 9       # per block: w1, a1, g1, b1, D, a2, g2, b2, w2  (order of include/ctn_hip.h)
+
+
+def composite_enabled():
+    return _COMPOSITE
+
+
+def _ptr_table(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def tcn_gln_infer(x0, K, dilations, causal, params):
+    """Forward of the stack without saving activations (torch.no_grad paths): two x slots, one h1 / d slot."""
+    nb = len(dilations)
+    M, B, Kp = x0.shape
+    H, P = params[0].shape[0], params[4].shape[-1]
+    dev = x0.device
+    _chk(x0, *params)
+    xs = torch.empty((2, M, B, Kp), dtype=F32, device=dev)
+    h1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+    d = torch.empty((M, H, Kp), dtype=F32, device=dev)
+    ms = torch.empty((2, M, 2), dtype=F32, device=dev)
+    nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp)
+    ws = _workspace(nbytes, dev, "tcn_fwd")
+    dil = (ctypes.c_int * nb)(*dilations)
+    lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1), _p(d), _p(ms), 0,
+             M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+    return xs[(nb - 1) & 1]
+
+
+class TcnGln(torch.autograd.Function):
+    """x0 [M,B,Kp] -> output of the last TemporalBlock; `params` = 9 tensors per block in NPARAM order."""
+
+    @staticmethod
+    def forward(ctx, x0, K, dilations, causal, *params):
+        nb = len(dilations)
+        if len(params) != nb * NPARAM:
+            raise ValueError("TcnGln: expected %d parameter tensors, got %d" % (nb * NPARAM, len(params)))
+        x0 = _c(x0)
+        M, B, Kp = x0.shape
+        H, P = params[0].shape[0], params[4].shape[-1]
+        if H % 4 or B % 4:
+            raise ValueError("HIP path needs B and H to be multiples of 4")
+        dev = x0.device
+        _chk(x0, *params)
+        xs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
+        h1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
+        ds = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
+        ms = torch.empty((nb, 2, M, 2), dtype=F32, device=dev)
+        nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp)
+        ws = _workspace(nbytes, dev, "tcn_fwd")
+        dil = (ctypes.c_int * nb)(*dilations)
+        lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms), 1,
+                 M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+        # our own buffers, written once and read once by backward: plain attributes (no version counters needed)
+        ctx.acts = (x0, xs, h1s, ds, ms)
+        ctx.params = params
+        ctx.cfg = (K, dil, nb, causal, P)
+        ctx.sinks = tuple(_sink(p) for p in params)
+        return xs[nb - 1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, xs, h1s, ds, ms = ctx.acts
+        params = ctx.params
+        K, dil, nb, causal, P = ctx.cfg
+        dout = _c(dout)
+        _, M, B, Kp = xs.shape
+        H = h1s.shape[2]
+        dev = x0.device
+        _chk(dout)
+        direct = all(s is not None for s in ctx.sinks)
+        if direct:
+            gdst, flat = ctx.sinks, None
+        else:                       # plain autograd parameters: gradients land in one scratch buffer, returned as views
+            sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+            flat = torch.empty((sum(sizes),), dtype=F32, device=dev)
+            gdst, o = [], 0
+            for p, n in zip(params, sizes):
+                gdst.append(flat[o:o + p.numel()].view(p.shape))
+                o += n
+        dxs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
+        dn1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
+        nbytes = lib.ctn_tcn_gln_bwd_workspace(M, B, H, Kp, P)
+        ws = _workspace(nbytes, dev, "tcn_bwd")
+        side = _side_stream(dev) if (direct and _SIDE_ENABLED) else None
+        lib.call("ctn_tcn_gln_bwd", _ptr_table(params), _ptr_table(gdst), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms),
+                 _p(dout), _p(dxs), _p(dn1s), M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(),
+                 0 if side is None else side.cuda_stream)
+        ctx.acts = None             # release 4 GB of saved activations as soon as they are consumed
+        # the call joined the side stream into the current one, so stream-ordered reuse of these buffers is safe
+        if direct:
+            return (dxs[0], None, None, None) + (None,) * len(params)
+        return (dxs[0], None, None, None) + tuple(gdst)
 
 
 # ---------------------------------------------------------------------------------------

@@ -80,35 +80,6 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * call before sizing workspaces */
 int ctn_tune_wgrad(int tile, int blocks);
 
-/* ---- split-bf16 ("x6") forms of the same GEMMs ------------------------------------------------
- * fp32-accurate products on the bf16 matrix cores: every fp32 operand is split exactly into three bf16 pieces and the
- * six piece-products of weight >= 2^-16 are accumulated in fp32 (dropped terms <= 2^-24 |a.b|).  Same contracts as the
- * fp32-MFMA entry points above; the weights are passed as pre-split planes made by ctn_split_bf16. */
-int ctn_split_cols(int Cn);                 /* contraction length padded to the kernels' k-tile (32) */
-/* planes: [3][R][ctn_split_cols(Cn)] bf16 with (R, Cn) = transpose ? (cols, rows) : (rows, cols); W is [rows, cols].
- * transpose = 1 prepares the input-gradient (W^T) form. */
-int ctn_split_bf16(const float* W, void* planes, int rows, int cols, int transpose, void* stream);
-int ctn_pw_gemm_x6(const void* Wp, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
-                   const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
-                   const float* pro_alpha, float* pro_ms_out,
-                   const float* residual, const float* epi_alpha, double* epi_part, int relu_out, void* stream);
-int ctn_pw_dgrad_gln_x6(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
-                        const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
-                        void* stream);
-int ctn_pw_wgrad_x6(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
-                    const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
-                    void* workspace, size_t workspace_bytes, void* stream);
-size_t ctn_pw_wgrad_x6_workspace(int M, int R, int Cn, int Kp);
-/* "p6": both operands already split in HBM.  ctn_split_act is the stand-alone form of what the producers' epilogues
- * emit (planes [3][n] bf16).  ctn_pw_gemm_p6: Out[m] = Wp(m) . Xp[m] (+ row_bias[m,r] for k < K) (+ residual), stored
- * as fp32 (Out) and / or as bf16 planes (out_planes [3][M,R,Kp]); Wp [3][R][Cnp], per utterance ([M][3][R][Cnp]) when
- * w_per_m != 0; one of the residual / PReLU-statistics / ReLU / gLN-backward epilogues as in the fp32 entry points. */
-int ctn_split_act(const float* X, void* planes, long long n, void* stream);
-int ctn_pw_gemm_p6(const void* Wp, int w_per_m, const void* Xp, float* Out, void* out_planes, int M, int R, int Cn,
-                   int K, int Kp, const float* row_bias, const float* residual, const float* epi_alpha, double* epi_part,
-                   int relu_out, const float* bwd_y, const float* bwd_gamma, const float* bwd_alpha, const float* bwd_ms,
-                   double* bwd_part, void* stream);
-
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
  * PReLU (:224,:259) and GlobalLayerNorm (:225,:260,:338-361) on either side fused in. */
@@ -147,6 +118,37 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
 int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
                       const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
                       float* dalpha_part, void* stream);
+
+/* ---- composite: the whole stack of gLN TemporalBlocks in one call ---------------------------------
+ * replaces `temporal_conv_net = nn.Sequential(*repeats)`, src/conv_tasnet.py:176-186, i.e. nblocks = X*R
+ * TemporalBlock.forward calls (:233-243) and their autograd backward.  The host side of a block (3 launches forward,
+ * 8 backward) is issued from C++ in exactly the order of the per-kernel entry points above, so results are bitwise
+ * those of calling them one by one.
+ *   params  : HOST array [nblocks][9] of device pointers, per block in the order
+ *             w1 [H,B], alpha1 [1], gamma1 [H], beta1 [H], D [H,P], alpha2 [1], gamma2 [H], beta2 [H], w2 [B,H]
+ *             (src/conv_tasnet.py:223-225 and :253-262).   grads: the same layout, gradient destinations.
+ *   dilation: HOST int [nblocks] (2^x, :170).
+ *   x0 [M,B,Kp]: input of block 0.  Forward writes, backward reads (all device, caller-owned):
+ *     xs  [nblocks][M,B,Kp]  block outputs (xs[nblocks-1] is the stack's output),
+ *     h1s [nblocks][M,H,Kp]  first 1x1 outputs,  ds [nblocks][M,H,Kp] depthwise outputs,
+ *     ms  [nblocks][2][M][2] (mean, rstd) of the two gLNs.
+ *     save = 0 (inference): xs needs 2 slots, h1s / ds / ms one slot each; the output is xs[(nblocks-1) & 1].
+ *   backward: dout [M,B,Kp] gradient of the stack's output; dxs [nblocks][M,B,Kp] receives the gradient of every
+ *     block's input (dxs[0] = gradient w.r.t. x0); dn1s [nblocks][M,H,Kp] scratch (one slot per block, read by the
+ *     weight-gradient stream).  side_stream != NULL: weight-gradient GEMMs go there (forked / joined with
+ *     ctn_stream_order); on return `stream` is ordered after all of them.
+ *   workspace: ctn_tcn_gln_{fwd,bwd}_workspace() bytes, 256-byte aligned. */
+int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
+                    float* xs, float* h1s, float* ds, float* ms, int save,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp);
+int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
+                    const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
+                    const float* dout, float* dxs, float* dn1s,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
+size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P);
 
 /* ---- channel-wise LayerNorm, src/conv_tasnet.py:313-335 (per frame, biased variance) -----
  * Out = gamma*((a-mean_k)*rstd_k)+beta with a = prelu(Y,alpha) if alpha != NULL else Y.

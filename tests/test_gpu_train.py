@@ -224,3 +224,33 @@ def test_graphed_backprop_replays_the_eager_step():
         opt = FlatAdam(model.parameters(), lr=1e-3)
         st = GraphedBackprop(model, opt, batches[0])
         st(batches[0][0][:1].to(DEV), batches[0][1][:1].to(DEV), batches[0][2][:1].to(DEV))
+
+
+@pytest.mark.parametrize("flat", [True, False])
+@pytest.mark.parametrize("causal", [False, True])
+def test_composite_stack_is_bitwise_the_per_kernel_path(flat, causal, monkeypatch):
+    """ctn_tcn_gln_fwd / ctn_tcn_gln_bwd (one C call per direction for the whole TemporalBlock stack, weight gradients on
+    the second stream) against the per-kernel entry points driven block by block from Python: outputs, loss and every
+    gradient must be bitwise equal -- the composite only moves the host side of the launches into C++."""
+    from conv_tasnet_amd import ops
+    mix, lens, src = O.synth_batch(5, 3, 4000 + 7)
+    res = []
+    for composite in (True, False):
+        monkeypatch.setattr(ops, "_COMPOSITE", composite)
+        torch.manual_seed(3)
+        m = ctn.ConvTasNet(32, 20, 16, 32, 3, 4, 2, 2, norm_type="gLN", causal=causal).to(DEV)
+        opt = FlatAdam(m.parameters(), lr=1e-3) if flat else None
+        if opt is not None:
+            opt.zero_grad()
+        est = m(mix.to(DEV))
+        loss = ctn.cal_loss(src.to(DEV), est, lens.to(DEV))[0]
+        loss.backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        res.append((est.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        with torch.no_grad():                      # the inference form (ping-pong slots) gives the same output too
+            assert torch.equal(m(mix.to(DEV)), res[-1][0])
+    (e1, l1, g1), (e2, l2, g2) = res
+    assert torch.equal(e1, e2) and torch.equal(l1, l2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
