@@ -52,9 +52,28 @@ def main():
         "B2 wgrad2 pro   R256 C512": lambda: ops.pw_wgrad(xB, xH, B, H, K, pro=(g, b, a, ms)),
         "-- fwd1 plain   R512 C256": lambda: ops.pw_gemm(w1, xB, H, B, K),
     }
+    if os.environ.get("CTN_PW_KERNEL", "1") == "2":       # persistent kernels: forward forms on a transposed weight copy
+        w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
+        cases.update({
+            "K1t fwd1 stats  W^T      ": lambda: ops.pw_gemm(w1t, xB, H, B, K, trans_w=True, epi_alpha=a),
+            "K3t fwd2 pro+res W^T     ": lambda: ops.pw_gemm(w2t, xH, B, H, K, trans_w=True, pro=(st2, g, b, a), residual=xB),
+            "--t fwd1 plain  W^T      ": lambda: ops.pw_gemm(w1t, xB, H, B, K, trans_w=True),
+        })
+    import ctypes
+    dll = ctn.lib.load()
+    has_clk = hasattr(dll, "ctn_debug_read")           # -DCTN_EXP_CLOCK builds
+    only = [c for c in os.environ.get("LAB_CASES", "").split(",") if c]
     for name, fn in cases.items():
+        if only and not any(name.startswith(c) for c in only):
+            continue
         us = timeit(fn)
-        print("%-22s %-28s %8.1f us %7.1f TFLOP/s  %.3f of peak" % (tag, name, us, flop / us / 1e6, flop / us / 1e6 / 157.3), flush=True)
+        clk = ""
+        if has_clk:
+            buf = (ctypes.c_ulonglong * 2)()
+            dll.ctn_debug_read(buf, 2)
+            if buf[1]:
+                clk = "  in-kernel clock %.2f GHz (wg 0 alive %.1f us)" % (buf[0] / buf[1] * 0.1, buf[1] / 100.0)
+        print("%-22s %-28s %8.1f us %7.1f TFLOP/s  %.3f of peak%s" % (tag, name, us, flop / us / 1e6, flop / us / 1e6 / 157.3, clk), flush=True)
 
 
 if __name__ == "__main__":

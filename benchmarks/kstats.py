@@ -5,7 +5,7 @@ import glob
 import sys
 
 d, steps = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 7.0
-f = glob.glob(d + "/*/*_kernel_stats.csv")[0]
+f = (glob.glob(d + "/*/*_kernel_stats.csv") + glob.glob(d + "/*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel time per step: %.2f ms" % (tot / 1e6 / steps))

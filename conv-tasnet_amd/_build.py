@@ -12,7 +12,9 @@ SOURCES = ["ctn_api.hip", "ctn_gemm.hip", "ctn_tcn.hip", "ctn_bn.hip", "ctn_code
 # opt-in experiment (split-bf16 GEMMs, include/ctn_hip_experimental.h): CTN_BUILD_X6=1
 if os.environ.get("CTN_BUILD_X6") == "1":
     SOURCES.append(os.path.join("experimental", "ctn_gemm_x6.hip"))
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("CTN_EXTRA_HIPCC_FLAGS", "").split()
+# -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs (unified file on gfx950), so the epilogues read them without
+# v_accvgpr_read copies -- every VALU instruction serialises with the fp32 MFMAs (profiles/r02_a_mfma_probe.txt)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("CTN_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

@@ -12,6 +12,9 @@
 // call ends by ordering `stream` after `side_stream`, so every gradient is complete in stream order when it returns.
 #include "ctn_common.h"
 #include "../../include/ctn_hip.h"
+#include <vector>
+
+extern "C" int ctn_pw_uses_pk(void);       // ctn_gemm.hip
 
 namespace {
 
@@ -20,16 +23,16 @@ enum { P_W1 = 0, P_A1, P_G1, P_B1, P_D, P_A2, P_G2, P_B2, P_W2, NPARAM };
 inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
 struct FwdWs {
-    size_t st1, st2, total;
+    size_t st1, st2, wt, total;
     int np1;
 };
-FwdWs fwd_ws(int M, int B, int H, int Kp) {
-    (void)B;
+FwdWs fwd_ws(int M, int B, int H, int Kp, int nblocks) {
     FwdWs w;
     w.np1 = ctn_pw_stats_parts(M, H, Kp);
     w.st1 = 0;
     w.st2 = align256((size_t)M * w.np1 * 2 * sizeof(double));
-    w.total = w.st2 + align256((size_t)M * H * 2 * sizeof(double));
+    w.wt = w.st2 + align256((size_t)M * H * 2 * sizeof(double));
+    w.total = w.wt + (size_t)nblocks * 2 * align256((size_t)H * B * sizeof(float));     // [nblocks][w1^T | w2^T]
     return w;
 }
 
@@ -58,7 +61,7 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P) {
 
 extern "C" {
 
-size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp) { return fwd_ws(M, B, H, Kp).total; }
+size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) { return fwd_ws(M, B, H, Kp, nblocks).total; }
 size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P) { return bwd_ws(M, B, H, Kp, P).total; }
 
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
@@ -67,7 +70,7 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
                     void* workspace, size_t workspace_bytes, void* stream) {
     CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && workspace, "ctn_tcn_gln_fwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_fwd: bad sizes");
-    const FwdWs w = fwd_ws(M, B, H, Kp);
+    const FwdWs w = fwd_ws(M, B, H, Kp, nblocks);
     if (workspace_bytes < w.total) {
         ctn_set_error("ctn_tcn_gln_fwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
         return CTN_ERR_WORKSPACE;
@@ -75,23 +78,45 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     double* const st1 = (double*)((char*)workspace + w.st1);
     double* const st2 = (double*)((char*)workspace + w.st2);
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
+    // [I, O] copies of both 1x1 weights of every block (the fast operand form of the persistent GEMM), one launch each
+    float* const wt = (float*)((char*)workspace + w.wt);
+    const size_t wsz = align256((size_t)H * B * sizeof(float)) / sizeof(float);
+    const bool use_wt = ctn_pw_uses_pk() != 0;      // the round-1 kernels (CTN_PW_KERNEL=1, A/B runs) take the stored weights
+    if (use_wt) {
+        std::vector<const void*> src(nblocks);
+        std::vector<void*> dst(nblocks);
+        for (int i = 0; i < nblocks; ++i) {
+            const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+            for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
+            src[i] = p[P_W1]; dst[i] = wt + (size_t)(2 * i) * wsz;
+        }
+        int rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, H, B, stream);          // w1 [H,B] -> [B,H]
+        if (rc) return rc;
+        for (int i = 0; i < nblocks; ++i) {
+            src[i] = ((const float* const*)(params + (size_t)i * NPARAM))[P_W2]; dst[i] = wt + (size_t)(2 * i + 1) * wsz;
+        }
+        rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, B, H, stream);              // w2 [B,H] -> [H,B]
+        if (rc) return rc;
+    }
     const float* x = x0;
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
+        const float* const w1t = use_wt ? wt + (size_t)(2 * i) * wsz : p[P_W1];
+        const float* const w2t = use_wt ? wt + (size_t)(2 * i + 1) * wsz : p[P_W2];
         // save = 0 (inference): one h1 / d slot and two ping-pong x slots; save = 1: a slot per block for the backward pass
         float* const h1 = h1s + (save ? (size_t)i * hsz : 0);
         float* const d = ds + (save ? (size_t)i * hsz : 0);
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const ms1 = ms + ((size_t)(save ? i : 0) * 2 + 0) * M * 2;
         float* const ms2 = ms + ((size_t)(save ? i : 0) * 2 + 1) * M * 2;
-        int rc = ctn_pw_gemm(p[P_W1], x, h1, M, H, B, K, Kp, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+        int rc = ctn_pw_gemm(w1t, x, h1, M, H, B, K, Kp, use_wt ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                              p[P_A1], st1, 0, stream);
         if (rc) return rc;
         rc = ctn_dw_fwd(h1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, st1, w.np1, p[P_G1], p[P_B1], p[P_A1], ms1,
                         p[P_A2], st2, stream);
         if (rc) return rc;
-        rc = ctn_pw_gemm(p[P_W2], d, out, M, B, H, K, Kp, 0, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
+        rc = ctn_pw_gemm(w2t, d, out, M, B, H, K, Kp, use_wt ? 1 : 0, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
                          stream);
         if (rc) return rc;
         x = out;

@@ -14,6 +14,7 @@
 // (64 cycles) consumes one A and one B dword per lane, so LDS bandwidth is
 // never the bound; the fused prologue/epilogue work rides in the VALU shadow.
 #include "ctn_gemm_common.h"
+#include <string.h>
 
 namespace {
 
@@ -181,6 +182,362 @@ __global__ __launch_bounds__(TL::NTH) void pw_gemm_kernel(PwArgs a) {
 #endif
 }
 
+
+// ===========================================================================================================
+// Persistent fp32-MFMA GEMM ("pk"): the product kernel of every 1x1 convolution in forward / input-gradient form.
+//
+// Cost model it is built on (benchmarks/mfma_probe.hip, profiles/r02_a_mfma_probe.txt): v_mfma_f32_32x32x2_f32 issues
+// at 64.9 cycles whatever the occupancy or chain count (154.5 TF), but on a SIMD it SERIALISES with every VALU
+// instruction of every resident wave (fp32 MFMA and fp32 VALU share the datapath: two waves, one MFMA-only and one
+// v_fma-only, take 0.87-1.0 of the SUM of their times; the bf16 MFMA overlaps the same VALU stream completely),
+// while LDS and vector-memory instructions overlap it.  A VALU burst between two MFMAs of one wave costs ~14 cycles
+// + ~4.7 per instruction.  So the kernel spends VALU instructions nowhere it can avoid them:
+//   * persistent workgroups: 64x64 output tiles dealt to gridDim.x resident workgroups, per-lane address registers
+//     are computed once per workgroup, per-tile offsets are scalar (SALU is free);
+//   * the k-tile pipeline (LDS double buffer + two register staging sets, prefetch distance 2) runs ACROSS tile
+//     boundaries: the first k-tiles of the next tile are in flight while the current tile finishes;
+//   * weights are read in [contraction][row] form (TRANS_W = 1: the forward pass gets a transposed copy), so both
+//     operands land in LDS as 16-byte row writes into UNPADDED 64-dword rows and every fragment read is a
+//     ds_read2st64_b32 with immediate offsets: the main loop has no VALU instruction;
+//   * the epilogue stores straight from the accumulators (two 128-byte row segments per store instruction), with
+//     residual / PReLU-statistics / gLN-backward sums computed on the accumulator registers; statistics leave as one
+//     (sum, sum of squares) partial per WAVE, reduced by DPP in fp32 -- no LDS round trip, no barrier.
+// ===========================================================================================================
+#ifdef CTN_EXP_CLOCK      // experiment builds only: in-kernel clock of the persistent GEMM (s_memtime / s_memrealtime)
+__device__ unsigned long long ctn_dbg[8];
+#endif
+
+struct PkTile {
+    int m, r0, c0, pidx;     // utterance, first row, first column, index of the tile within the utterance (ct * tiles_r + rt)
+};
+
+// (mean, rstd) of one utterance from [nparts][2] fp64 partials, computed redundantly by every wave (no LDS, no barrier)
+__device__ __forceinline__ void finalize_stats_wave(const double* __restrict__ part, int nparts, double count, float& mean,
+                                                    float& rstd) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x & 63; i < nparts; i += 64) {
+        s += part[2 * i];
+        q += part[2 * i + 1];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const double mu = s / count;
+    double var = q / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)CTN_EPS));
+}
+
+// experiment hooks (benchmarks/gemm_lab.py builds; never defined in the product build)
+#ifdef CTN_EXP_NO_BARRIER
+#define PK_SYNC() __builtin_amdgcn_s_waitcnt(0xc07f)   /* lgkmcnt(0) only */
+#else
+#define PK_SYNC() __syncthreads()
+#endif
+#ifdef CTN_EXP_NO_LDS_READ
+#define PK_A(off) xa0
+#define PK_B(off) xb0
+#else
+#define PK_A(off) fA[off]
+#define PK_B(off) fB[off]
+#endif
+
+// WT = MFMA tiles per wave edge: WT = 1 -> 64x64 workgroup tile (32x32 per wave), WT = 2 -> 128x128 (64x64 per wave: half
+// the LDS-read and global-load bytes per MFMA -- the kernel is power-limited, energy per MFMA sets the clock).
+template <int TRANS_W, int PRO, int EPI, int WT>
+__global__ __launch_bounds__(256) void pw_gemm_pk_kernel(PwArgs a, unsigned long long magic_r, unsigned long long magic_c) {
+    constexpr int TM = 64 * WT, TN = 64 * WT, BK = 16, WS = 32 * WT;           // WS: wave sub-tile edge
+    constexpr int LDA = TRANS_W ? TM : TM + 4, LDB = TN;
+    constexpr int TPR = TN / 4;                  // threads per 16-byte-chunked row of a [k][TM | TN] tile
+    constexpr int RPP = 256 / TPR;               // k-rows per pass; WT passes cover the BK = 16 rows
+    static_assert(RPP * WT == BK, "tile / thread map");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
+    float* const As = smem;                       // [2][BK][LDA]
+    float* const Bs = smem + 2 * BK * LDA;        // [2][BK][LDB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- this workgroup's tiles: XCD x owns a contiguous range of tile indices (rows fastest, then column tiles, then
+    // utterances), dealt round-robin to its workgroups -- at any time an XCD works on consecutive tiles, whose row tiles
+    // re-read the same activation columns from its own L2 ------------------------------------------------------------
+    const int ntm = a.tiles_r * a.tiles_c, ntiles = ntm * a.M;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int lo = xcd * q8 + (xcd < r8 ? xcd : r8), cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);                   // workgroups on this XCD
+    const int ntl = slot < cnt ? (cnt - slot + gx - 1) / gx : 0;          // tiles of this workgroup
+    if (ntl == 0) return;
+#ifdef CTN_EXP_CLOCK
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    auto decode = [&](int j) {
+        PkTile t;
+        const unsigned id = (unsigned)(lo + slot + j * gx);
+        const unsigned u = (unsigned)(((unsigned long long)id * magic_r) >> 32);    // id / tiles_r  (magic = ceil(2^32 / d):
+        const unsigned rt = id - u * (unsigned)a.tiles_r;                            //  exact while id * d < 2^32, checked by the host)
+        const unsigned mm = (unsigned)(((unsigned long long)u * magic_c) >> 32);     // u / tiles_c
+        const unsigned ct = u - mm * (unsigned)a.tiles_c;
+        t.m = (int)mm; t.r0 = (int)rt * TM; t.c0 = (int)ct * TN; t.pidx = (int)(ct * (unsigned)a.tiles_r + rt);
+        return t;
+    };
+
+    // ---- per-lane address registers, once per workgroup -----------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)a.R * (unsigned)a.Cn * 4u);
+    const unsigned xbytes = (unsigned)a.Cn * (unsigned)a.Kp * 4u, obytes = (unsigned)a.R * (unsigned)a.Kp * 4u;
+    // A: TRANS_W=1 reads W[c + RPP j][r0 + r4 ..+3]: c = tid / TPR, r4 = (tid % TPR) * 4;
+    //    TRANS_W=0 reads W[r0 + r + 64 j][c4 ..+3]: r = tid / 4, c4 = (tid % 4) * 4
+    // B: X[i + RPP j][c0 + k4 ..+3]: i = tid / TPR, k4 = (tid % TPR) * 4
+    const int a_r4 = (tid % TPR) * 4, rowk = tid / TPR;
+    const int voA = TRANS_W ? (rowk * a.R + a_r4) * 4 : ((tid >> 2) * a.Cn + (tid & 3) * 4) * 4;
+    const int jA = TRANS_W ? RPP * a.R * 4 : 64 * a.Cn * 4;               // byte step between the WT loads of a thread
+    const int voB = (rowk * a.Kp + a_r4) * 4, jB = RPP * a.Kp * 4;
+    const int voP = rowk * 4;                                              // gamma / beta of channel i (+ RPP j)
+    const int sAk = (TRANS_W ? BK * a.R : BK) * 4, sBk = BK * a.Kp * 4;    // scalar byte steps per k-tile
+    __amdgpu_buffer_rsrc_t rsG = rsW, rsBt = rsW;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        rsG = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
+        rsBt = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
+    }
+    // LDS: store slots (A row write / transposing scatter, B row write) and fragment bases
+    float* const stA = TRANS_W ? As + rowk * LDA + a_r4 : As + ((tid & 3) * 4) * LDA + (tid >> 2);
+    float* const stB = Bs + rowk * LDB + a_r4;
+    const float* const fA = As + lhi * LDA + wm * WS + l31;
+    const float* const fB = Bs + lhi * LDB + wn * WS + l31;
+    // epilogue: element e of a 32x32 C/D map sits at row (e&3) + 8*(e>>2) + 4*lhi, column l31 of the sub-tile
+    const int voE = ((wm * WS + 4 * lhi) * a.Kp + wn * WS + l31) * 4;
+
+    float p_alpha = 0.f, e_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) p_alpha = a.pro_alpha[0];
+    if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
+    if constexpr (EPI == EPI_GLN_BWD) e_alpha = a.bwd_alpha[0];
+
+    // k-tiles per tile, rounded up to even so that tile boundaries coincide with the two-k-tile software pipeline (an odd
+    // count gets one k-tile past the contraction: both operands read zeros there -- buffer range check)
+    const int nk = (((a.Cn + BK - 1) / BK) + 1) & ~1;
+
+    struct Stage { float4 a[WT], b[WT]; float2 p[WT]; };
+
+    // ---- load cursor (two k-tiles ahead of the compute cursor; crosses tile boundaries) ------------------------------
+    PkTile lt = decode(0);
+    int lj = 0, lkt = 0;
+    __amdgpu_buffer_rsrc_t rsXl = make_rsrc(a.X + (size_t)lt.m * a.Cn * a.Kp, xbytes);
+    auto load_next = [&](Stage& r) {     // loads k-tile (lj, lkt), then advances
+        if (lj < ntl) {
+            const int sA = (TRANS_W ? lt.r0 : lt.r0 * a.Cn) * 4 + lkt * sAk;
+#ifndef CTN_EXP_NO_GLOBAL
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                r.a[j] = buf_ld4(rsW, voA, sA + j * jA);
+                r.b[j] = buf_ld4(rsXl, voB, lt.c0 * 4 + lkt * sBk + j * jB);
+            }
+#else
+            (void)sA;
+#endif
+            if constexpr (PRO == PRO_PRELU_NORM) {
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    r.p[j] = make_float2(buf_ld1(rsG, voP, (lkt * BK + j * RPP) * 4), buf_ld1(rsBt, voP, (lkt * BK + j * RPP) * 4));
+            }
+            if (++lkt == nk) {
+                lkt = 0;
+                if (++lj < ntl) {
+                    const int m_old = lt.m;
+                    lt = decode(lj);
+                    if (lt.m != m_old) rsXl = make_rsrc(a.X + (size_t)lt.m * a.Cn * a.Kp, xbytes);
+                }
+            }
+        }
+    };
+
+    // ---- store cursor = compute cursor + 1 k-tile: the k-tile being written to LDS (prologue constants follow it) ----
+    int sm = -1, skt = 0, sj = 0;
+    PkTile stt = lt;
+    float p_mean = 0.f, p_rstd = 1.f;
+    auto store_tile = [&](int buf, const Stage& r) {       // writes k-tile (sj, skt), then advances
+        if (sj >= ntl) return;
+        if constexpr (PRO == PRO_PRELU_NORM) {
+            if (stt.m != sm) {                       // a new utterance: its (mean, rstd) from the producer's partials
+                sm = stt.m;
+                finalize_stats_wave(a.pro_part + (size_t)sm * a.pro_nparts * 2, a.pro_nparts, (double)a.Cn * (double)a.K,
+                                    p_mean, p_rstd);
+            }
+            if (a.pro_ms_out != nullptr && skt == 0 && stt.pidx == 0 && tid == 0) {     // the utterance's first tile publishes them
+                a.pro_ms_out[2 * sm] = p_mean;
+                a.pro_ms_out[2 * sm + 1] = p_rstd;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+            if constexpr (TRANS_W == 1) {
+                *reinterpret_cast<float4*>(stA + buf * BK * LDA + j * RPP * LDA) = r.a[j];
+            } else {
+                float* const d = stA + buf * BK * LDA + j * 64;
+                d[0] = r.a[j].x; d[LDA] = r.a[j].y; d[2 * LDA] = r.a[j].z; d[3 * LDA] = r.a[j].w;
+            }
+            float4 rb = r.b[j];
+            if constexpr (PRO == PRO_PRELU_NORM) rb = pro_apply(rb, stt.c0 + a_r4, a.K, r.p[j].x, r.p[j].y, p_alpha, p_mean, p_rstd);
+            *reinterpret_cast<float4*>(stB + buf * BK * LDB + j * RPP * LDB) = rb;
+        }
+        if (++skt == nk) {
+            skt = 0;
+            if (++sj < ntl) stt = decode(sj);
+        }
+    };
+
+    // ---- pipeline: LDS buffer g & 1 holds k-tile g of the flattened (tile, k-tile) sequence, register set P the next odd
+    // one, Q the next even one ------------------------------------------------------------------------------------------
+    Stage P, Q;
+#ifdef CTN_EXP_NO_GLOBAL
+#pragma unroll
+    for (int j = 0; j < WT; ++j) P.a[j] = P.b[j] = Q.a[j] = Q.b[j] = make_float4(1.f, 2.f, 3.f, 4.f);
+#endif
+#pragma unroll
+    for (int j = 0; j < WT; ++j) P.p[j] = Q.p[j] = make_float2(0.f, 0.f);
+    load_next(P);                 // g = 0
+    store_tile(0, P);
+    load_next(P);                 // g = 1 -> P
+    load_next(Q);                 // g = 2 -> Q
+    PK_SYNC();
+
+    f32x16 acc[WT][WT];
+    auto mma = [&](int off_a, int off_b, bool first) {       // one k-tile out of LDS (offsets of the buffer in floats)
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float av[WT], bv[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) av[i] = PK_A(off_a + 2 * s * LDA + 32 * i);
+#pragma unroll
+            for (int j = 0; j < WT; ++j) bv[j] = PK_B(off_b + 2 * s * LDB + 32 * j);
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) {
+                    if (first && s == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], zero, 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+#ifdef CTN_EXP_NO_LDS_READ
+    const float xa0 = fA[0], xb0 = fB[0];
+#endif
+
+    for (int cj = 0; cj < ntl; ++cj) {
+        const PkTile cur = decode(cj);
+        // first k-tile pair peeled: the accumulators start from the zero C operand of the first MFMA (no register clears),
+        // and the steady-state loop below stays a plain counted loop (the accumulators then live in one register range)
+        mma(0, 0, true);
+        store_tile(1, P);
+        PK_SYNC();
+        load_next(P);
+        mma(BK * LDA, BK * LDB, false);
+        store_tile(0, Q);
+        PK_SYNC();
+        load_next(Q);
+        for (int kt = 2; kt < nk; kt += 2) {
+            mma(0, 0, false);
+            store_tile(1, P);
+            PK_SYNC();
+            load_next(P);
+            mma(BK * LDA, BK * LDB, false);
+            store_tile(0, Q);
+            PK_SYNC();
+            load_next(Q);
+        }
+
+        // ---- epilogue, straight from the accumulators (the next tile's first k-tile is already in LDS, the two after it
+        // are in flight) -----------------------------------------------------------------------------------------------
+        const size_t mbase = (size_t)cur.m * a.R * a.Kp;
+        const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, obytes);
+        __amdgpu_buffer_rsrc_t rsAux = rsOut, rsGam = rsOut;
+        float b_mean = 0.f, b_rstd = 1.f;
+        if constexpr (EPI == EPI_RESIDUAL) rsAux = make_rsrc(a.residual + mbase, obytes);
+        if constexpr (EPI == EPI_GLN_BWD) {
+            rsAux = make_rsrc(a.bwd_y + mbase, obytes);
+            rsGam = make_rsrc(a.bwd_gamma, (unsigned)a.R * 4u);
+            b_mean = a.bwd_ms[2 * cur.m];
+            b_rstd = a.bwd_ms[2 * cur.m + 1];
+        }
+        float s1 = 0.f, s2 = 0.f;
+        const bool ovr = TRANS_W == 1 && cur.r0 + TM > a.R;       // uniform: rows >= R hold finite garbage (next contraction row)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const int sE = ((cur.r0 + 32 * i) * a.Kp + cur.c0 + 32 * j) * 4;             // scalar byte offset of the sub-tile
+                float aux[16], gam[16];
+                if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_GLN_BWD) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) aux[e] = buf_ld1(rsAux, voE, sE + ((e & 3) + 8 * (e >> 2)) * a.Kp * 4);
+                }
+                if constexpr (EPI == EPI_GLN_BWD) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        gam[e] = buf_ld1(rsGam, (wm * WS + 4 * lhi) * 4, (cur.r0 + 32 * i + (e & 3) + 8 * (e >> 2)) * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e];
+                    if constexpr (EPI == EPI_RESIDUAL) v += aux[e];
+                    if constexpr (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                    if constexpr (EPI == EPI_GLN_BWD) {
+                        const float t = gam[e] * v;
+                        const float xh = (prelu_f(aux[e], e_alpha) - b_mean) * b_rstd;
+                        s1 += t;
+                        s2 = fmaf(t, xh, s2);
+                    }
+#ifndef CTN_EXP_NO_STORE
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsOut, voE, sE + ((e & 3) + 8 * (e >> 2)) * a.Kp * 4, 0);
+#else
+                    if (v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsOut, voE, sE, 0);
+#endif
+                }
+                if constexpr (EPI == EPI_PRELU_STATS) {
+                    // only the statistics must not see the garbage rows of a row-overhang tile (their stores are dropped by the
+                    // range check).  A real branch, kept out of the common path (the asm stops if-conversion into selects).
+                    if (ovr) {
+                        asm volatile("; row-overhang tile" ::: "memory");
+                        const int rl = cur.r0 + wm * WS + 32 * i + 4 * lhi;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = (rl + (e & 3) + 8 * (e >> 2) < a.R) ? prelu_f(acc[i][j][e], e_alpha) : 0.f;
+                            s1 += p;
+                            s2 = fmaf(p, p, s2);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float p = prelu_f(acc[i][j][e], e_alpha);
+                            s1 += p;
+                            s2 = fmaf(p, p, s2);
+                        }
+                    }
+                }
+            }
+        if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) {
+                double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
+                              (((size_t)cur.m * ntm + cur.pidx) * 4 + wave) * 2;
+                dst[0] = (double)s1;
+                dst[1] = (double)s2;
+            }
+        }
+    }
+#ifdef CTN_EXP_CLOCK
+    if (blockIdx.x == 0 && tid == 0) {
+        ctn_dbg[0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        ctn_dbg[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    }
+#endif
+}
+
 template <int PRO, int WTM, int WTN>     // WTM x WTN output tile (multiples of 64), waves 2x2, (WTM/64)*(WTN/64) accumulator chains per wave
 __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
     constexpr int HTM = WTM / 2, HTN = WTN / 2;             // wave tile
@@ -324,7 +681,106 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
         }
 }
 
-// Split-bf16 weight gradient: both operands are activations (contraction = frames, contiguous in memory), so both
+// ---- weight gradient, second form ("w4"): 16-byte LDS traffic and no VALU in the main loop -----------------------------
+// Both operands are [channel][frame] with the contraction (frames) contiguous, so a lane can fetch four consecutive
+// contraction steps of its row with ONE ds_read_b128 -- if the k index of the MFMA chain is permuted: in the 8-frame
+// group j, MFMA i (i = 0..3) multiplies frame 8j + i in lanes 0-31 and frame 8j + 4 + i in lanes 32-63 (the two k
+// slots of v_mfma_f32_32x32x2_f32).  Any bijection of the contraction index is a valid GEMM; A and B use the same one.
+// LDS rows are 20 floats (80 B): 16-byte aligned for ds_write_b128 / ds_read_b128 and conflict-free over the 16-lane
+// groups of a b128 read.  Per 16-frame k-tile and wave: 8 MFMAs, 4 ds_read_b128, 2 ds_write_b128, 2 buffer loads.
+constexpr int W4LD = 20;
+
+template <int PRO>
+__global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][64][W4LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64][W4LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);          // the tiles of one split share their frames: one XCD, one L2
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c; bid /= a.tiles_c;
+    const int sp = bid;
+    const int m = sp / a.chunks_per_m, ch = sp % a.chunks_per_m;
+    const int kb = ch * a.chunk;
+    const int ke = min(kb + a.chunk, a.Kp);
+    const int r0 = rt * 64, c0 = ct * 64;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        p_mean = a.pro_ms[2 * m];
+        p_rstd = a.pro_ms[2 * m + 1];
+        p_alpha = a.pro_alpha[0];
+    }
+    const int nk = (ke - kb + WK - 1) / WK;
+    const __amdgpu_buffer_rsrc_t rsG = make_rsrc(a.dOut + (size_t)m * a.R * a.Kp, (unsigned)a.R * (unsigned)a.Kp * 4u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.X + (size_t)m * a.Cn * a.Kp, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
+    const int row = tid >> 2, kq = (tid & 3) * 4;
+    const int voG = ((r0 + row) * a.Kp + kq) * 4, voX = ((c0 + row) * a.Kp + kq) * 4;      // rows past R / Cn read 0 (range check)
+    float2 rg = make_float2(0.f, 0.f);
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        const __amdgpu_buffer_rsrc_t rsGa = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
+        const __amdgpu_buffer_rsrc_t rsBe = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
+        rg = make_float2(buf_ld1(rsGa, (c0 + row) * 4, 0), buf_ld1(rsBe, (c0 + row) * 4, 0));
+    }
+    auto load_tile = [&](int kt, float4& ra, float4& rb) {
+        const int so = (kb + kt * WK) * 4;
+        ra = buf_ld4(rsG, voG, so);
+        rb = buf_ld4(rsX, voX, so);
+    };
+    auto store_tile = [&](int buf, int kt, float4 ra, float4 rb) {      // (whole k-tiles only: the host requires Kp % 16 == 0)
+        if constexpr (PRO == PRO_PRELU_NORM) rb = pro_apply(rb, kb + kt * WK + kq, a.K, rg.x, rg.y, p_alpha, p_mean, p_rstd);
+        *reinterpret_cast<float4*>(&As[buf][row][kq]) = ra;
+        *reinterpret_cast<float4*>(&Bs[buf][row][kq]) = rb;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const float* const fA = &As[0][wm * 32 + l31][4 * lhi];
+    const float* const fB = &Bs[0][wn * 32 + l31][4 * lhi];
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < WK / 8; ++j) {
+            const float4 av = *reinterpret_cast<const float4*>(fA + buf * 64 * W4LD + 8 * j);
+            const float4 bv = *reinterpret_cast<const float4*>(fB + buf * 64 * W4LD + 8 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+    };
+    // prefetch distance 2: k-tile kt+1 waits in one register set, kt+2 is in flight into the other
+    float4 pa, pb, qa, qb;
+    if (nk > 0) {
+        load_tile(0, pa, pb);
+        store_tile(0, 0, pa, pb);
+        if (nk > 1) load_tile(1, pa, pb);
+        if (nk > 2) load_tile(2, qa, qb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0);
+        if (kt + 1 < nk) store_tile(1, kt + 1, pa, pb);
+        __syncthreads();
+        if (kt + 3 < nk) load_tile(kt + 3, pa, pb);
+        if (kt + 1 < nk) {
+            compute(1);
+            if (kt + 2 < nk) store_tile(0, kt + 2, qa, qb);
+            __syncthreads();
+            if (kt + 4 < nk) load_tile(kt + 4, qa, qb);
+        }
+    }
+    // slab [split][R][Cn]: two 128-byte row segments per store instruction, rows / columns past the matrix dropped
+    const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.slab + (size_t)sp * a.R * a.Cn, (unsigned)a.R * (unsigned)a.Cn * 4u);
+    const int c = c0 + wn * 32 + l31;
+    const int voS = c < a.Cn ? ((r0 + wm * 32 + 4 * lhi) * a.Cn + c) * 4 : 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float v = acc[e];       // (clang lowers __builtin_bit_cast of a vector ELEMENT to element 0: go through a scalar)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsS, voS, ((e & 3) + 8 * (e >> 2)) * a.Cn * 4, 0);
+    }
+}
+
 }  // namespace
 
 int g_ctn_tile_override = -2;
@@ -344,6 +800,113 @@ static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, b
     else if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (relu) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+}
+
+// ---- weight transposes for the forward pass --------------------------------------------------------------------
+// The persistent GEMM wants weights as [contraction][row] (16-byte row writes into unpadded LDS, no transposing
+// scatter).  The input-gradient GEMMs read the stored [O, I] matrices that way as they are; the forward GEMMs get a
+// transposed copy, refreshed once per step: up to 64 equally shaped matrices per launch, pointers by value.
+namespace {
+constexpr int TR_MAX = 64;
+struct TrArgs {
+    const float* src[TR_MAX];
+    float* dst[TR_MAX];
+    int rows, cols;
+};
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TrArgs a) {
+    __shared__ float t[32][33];
+    const float* __restrict__ S = a.src[blockIdx.z];
+    float* __restrict__ D = a.dst[blockIdx.z];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        if (r < a.rows && c < a.cols) t[ty + 8 * j][tx] = S[(size_t)r * a.cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (r < a.rows && c < a.cols) D[(size_t)c * a.rows + r] = t[tx][ty + 8 * j];
+    }
+}
+}  // namespace
+
+extern "C" int ctn_transpose_batch(const void* const* src, void* const* dst, int n, int rows, int cols, void* stream) {
+    CTN_REQUIRE(src && dst && n > 0 && rows > 0 && cols > 0, "ctn_transpose_batch: bad arguments");
+    for (int o = 0; o < n; o += TR_MAX) {
+        TrArgs a{};
+        const int cnt = n - o < TR_MAX ? n - o : TR_MAX;
+        for (int i = 0; i < cnt; ++i) {
+            CTN_REQUIRE(src[o + i] && dst[o + i], "ctn_transpose_batch: null matrix %d", o + i);
+            a.src[i] = (const float*)src[o + i];
+            a.dst[i] = (float*)dst[o + i];
+        }
+        a.rows = rows; a.cols = cols;
+        hipLaunchKernelGGL(transpose_batch_kernel, dim3(ctn_cdiv(cols, 32), ctn_cdiv(rows, 32), cnt), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    }
+    CTN_CHECK_LAUNCH("ctn_transpose_batch");
+    return CTN_OK;
+}
+
+#ifdef CTN_EXP_CLOCK
+extern "C" int ctn_debug_read(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ctn_dbg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---- persistent kernel: selection and launch ---------------------------------------------------------------
+// Default: the one-tile-per-workgroup kernels (pw_gemm_kernel).  The persistent kernels are 5-13 % faster launched alone
+// (K1 73 -> 63 us, plain 64 -> 57 us, profiles/r02_*) but do NOT win inside the training step: in-process A/B
+// (benchmarks/ab_step.py) 15.60 ms/step with pw_gemm_kernel against 16.0-16.4 ms with the persistent kernels at 3-8
+// resident workgroups per CU or one tile per workgroup -- the step is at the 1400 W package power cap (1346-1350 W
+// measured), the backward pass is the sum of its four GEMMs, and hardware-dispatched short workgroups interleave better
+// with the concurrent weight-gradient stream.  CTN_PW_KERNEL=2 selects them (kept with their tests for the next round).
+static int g_pk = -1, g_pk_wgs = 4, g_pk_wt = 1;     // 4 resident workgroups per CU leave room for the concurrent weight-gradient stream
+static bool use_pk() {
+    if (g_pk < 0) {
+        const char* e = getenv("CTN_PW_KERNEL");
+        g_pk = (e && *e && atoi(e) == 2) ? 1 : 0;
+        const char* w = getenv("CTN_PK_WGS");
+        if (w && *w && atoi(w) >= 0 && atoi(w) <= 16) g_pk_wgs = atoi(w);
+        const char* t = getenv("CTN_PK_WT");
+        if (t && *t && atoi(t) == 2) g_pk_wt = 2;
+    }
+    return g_pk == 1;
+}
+
+template <int TW, int WT>
+static void launch_pk_t(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, dim3 grid, hipStream_t st,
+                        unsigned long long mr, unsigned long long mc) {
+    const dim3 block(256);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_pk_kernel<1, PRO_NONE, EPI_GLN_BWD, WT>), grid, block, 0, st, a, mr, mc);
+    else if (pro) {
+        if (residual) hipLaunchKernelGGL((pw_gemm_pk_kernel<TW, PRO_PRELU_NORM, EPI_RESIDUAL, WT>), grid, block, 0, st, a, mr, mc);
+        else hipLaunchKernelGGL((pw_gemm_pk_kernel<TW, PRO_PRELU_NORM, EPI_NONE, WT>), grid, block, 0, st, a, mr, mc);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_pk_kernel<TW, PRO_NONE, EPI_PRELU_STATS, WT>), grid, block, 0, st, a, mr, mc);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_pk_kernel<TW, PRO_NONE, EPI_RESIDUAL, WT>), grid, block, 0, st, a, mr, mc);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_pk_kernel<TW, PRO_NONE, EPI_RELU, WT>), grid, block, 0, st, a, mr, mc);
+    else hipLaunchKernelGGL((pw_gemm_pk_kernel<TW, PRO_NONE, EPI_NONE, WT>), grid, block, 0, st, a, mr, mc);
+}
+
+static int launch_pk(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const int wt = (trans_w && g_pk_wt == 2 && a.Kp % 128 == 0) ? 2 : 1;      // 128x128 tiles: W^T form, whole column tiles only
+    a.tiles_r = ctn_cdiv(a.R, 64 * wt);
+    a.tiles_c = ctn_cdiv(a.Kp, 64 * wt);
+    const long long ntiles = (long long)a.tiles_r * a.tiles_c * a.M;
+    const int tmax = a.tiles_r > a.tiles_c ? a.tiles_r : a.tiles_c;
+    CTN_REQUIRE(ntiles * tmax < (1ll << 32), "ctn_pw_gemm: too many tiles for the 32-bit tile decode (%lld x %d)", ntiles, tmax);
+    const unsigned long long mr = ((1ull << 32) + (unsigned)a.tiles_r - 1) / (unsigned)a.tiles_r;
+    const unsigned long long mc = ((1ull << 32) + (unsigned)a.tiles_c - 1) / (unsigned)a.tiles_c;
+    long long g8 = (ntiles + 7) / 8;
+    if (g_pk_wgs > 0 && g8 > 32ll * g_pk_wgs) g8 = 32ll * g_pk_wgs;     // 32 CUs per XCD, g_pk_wgs resident workgroups per CU
+                                                                        // (g_pk_wgs = 0: one tile per workgroup, hardware dispatch)
+    const dim3 grid((unsigned)(8 * g8));
+    if (wt == 2) launch_pk_t<1, 2>(a, pro, residual, stats, relu, gln_bwd, grid, st, mr, mc);
+    else if (trans_w) launch_pk_t<1, 1>(a, pro, residual, stats, relu, gln_bwd, grid, st, mr, mc);
+    else launch_pk_t<0, 1>(a, pro, residual, stats, relu, gln_bwd, grid, st, mr, mc);
+    return CTN_OK;
 }
 
 static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
@@ -375,7 +938,11 @@ int ctn_tune_pw_tile(int id) {
     return CTN_OK;
 }
 
+// internal (ctn_block.hip): 1 when the persistent kernels are active, i.e. fused prologue / statistics work with trans_w = 1
+int ctn_pw_uses_pk(void) { return use_pk() ? 1 : 0; }
+
 int ctn_pw_stats_parts(int M, int R, int Kp) {
+    if (use_pk()) return ctn_cdiv(R, 64) * ctn_cdiv(Kp, 64) * 4;      // >= one partial per wave of every tile (64x64 tiles: exactly)
     int tm, tn;
     tile_dims(pick_tile(M, R, Kp), &tm, &tn);
     return ctn_cdiv(R, tm) * ctn_cdiv(Kp, tn);
@@ -392,7 +959,7 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     CTN_REQUIRE(!(residual && epi_part), "ctn_pw_gemm: residual and stats epilogues are exclusive");
     CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0), "ctn_pw_gemm: incomplete prologue arguments");
     CTN_REQUIRE(!epi_part || epi_alpha, "ctn_pw_gemm: stats epilogue needs alpha");
-    CTN_REQUIRE(!(trans_w && (pro_part || epi_part)), "ctn_pw_gemm: fused prologue/stats only with trans_w=0");
+    CTN_REQUIRE(use_pk() || !(trans_w && (pro_part || epi_part)), "ctn_pw_gemm: fused prologue/stats only with trans_w=0");
     CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm: residual must be 16-byte aligned");
     PwArgs a{};
     a.store_f32 = 1;
@@ -400,8 +967,14 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
     a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
-    launch_fwd(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
-               (hipStream_t)stream);
+    if (use_pk()) {
+        rc = launch_pk(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
+                       (hipStream_t)stream);
+        if (rc) return rc;
+    } else {
+        launch_fwd(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
+                   (hipStream_t)stream);
+    }
     CTN_CHECK_LAUNCH("ctn_pw_gemm");
     return CTN_OK;
 }
@@ -419,7 +992,12 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
     a.store_f32 = 1;
     a.W = W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
-    launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
+    if (use_pk()) {
+        rc = launch_pk(a, 1, false, false, false, false, true, (hipStream_t)stream);
+        if (rc) return rc;
+    } else {
+        launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
+    }
     CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln");
     return CTN_OK;
 }
@@ -428,6 +1006,7 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
 
 extern "C" {
 
+static int g_w4 = -1;             // weight-gradient kernel: 1 = "w4" (16-byte LDS traffic), 0 = the round-1 kernel
 static int g_wgrad_tile = 0;      // 0: heuristic; 64, 128: square tiles; 12864: 128 x 64 (ctn_tune_wgrad)
 static int g_wgrad_blocks = 512;   // target workgroups per launch
 
@@ -452,6 +1031,20 @@ static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int*
     *tile = wt;
     *chunk = c;
     *chunks_per_m = ctn_cdiv(Kp, c);
+}
+
+// experiment hook for in-process A/B runs (benchmarks/ab_step.py): the same switches the CTN_* environment variables set
+// once at first use.  Keys: "pk" (1 persistent GEMMs, 0 round-1 kernels), "pk_wgs" (resident workgroups per CU),
+// "wgrad_kernel" (1 w4, 0 round-1), "wgrad_blocks" (target workgroups per weight-gradient launch).
+int ctn_tune(const char* key, int value) {
+    if (!key) return CTN_ERR_ARG;
+    use_pk();                                   // read the environment defaults first
+    if (!strcmp(key, "pk")) g_pk = value ? 1 : 0;
+    else if (!strcmp(key, "pk_wgs") && value >= 0 && value <= 16) g_pk_wgs = value;
+    else if (!strcmp(key, "wgrad_kernel")) g_w4 = value ? 1 : 0;
+    else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
+    else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
+    return CTN_OK;
 }
 
 int ctn_tune_wgrad(int tile, int blocks) {
@@ -489,7 +1082,12 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     a.pro_gamma = pro_gamma; a.pro_beta = pro_beta; a.pro_alpha = pro_alpha; a.pro_ms = pro_ms;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(NT);
-    if (wt == 64) {
+    if (g_w4 < 0) { const char* e = getenv("CTN_WGRAD_KERNEL"); g_w4 = (e && *e && atoi(e) == 1) ? 0 : 1; }   // 1 = the round-1 kernel (A/B runs)
+    const int w4 = g_w4;
+    if (wt == 64 && w4 && Kp % WK == 0) {
+        if (pro_ms) hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_PRELU_NORM>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_NONE>), grid, block, 0, st, a);
+    } else if (wt == 64) {
         if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 64, 64>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 64, 64>), grid, block, 0, st, a);
     } else if (wt == 12864) {
@@ -501,7 +1099,7 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     }
     CTN_CHECK_LAUNCH("ctn_pw_wgrad");
     const long long n = (long long)R * Cn;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n, NT)), block, 0, st, a.slab, nsplit, n, dW);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n / 4, NT)), block, 0, st, a.slab, nsplit, n, dW);   // R, Cn multiples of 4
     CTN_CHECK_LAUNCH("ctn_pw_wgrad/reduce");
     return CTN_OK;
 }

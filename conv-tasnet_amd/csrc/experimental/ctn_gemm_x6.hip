@@ -959,7 +959,7 @@ int ctn_pw_wgrad_x6(const float* dOut, const float* X, float* dW, int M, int R, 
     else hipLaunchKernelGGL((pw_wgrad_x6_kernel<PRO_NONE>), grid, block, 0, st, a);
     CTN_CHECK_LAUNCH("ctn_pw_wgrad_x6");
     const long long n = (long long)R * Cn;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n, NT)), block, 0, st, a.slab, nsplit, n, dW);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n / 4, NT)), block, 0, st, a.slab, nsplit, n, dW);
     CTN_CHECK_LAUNCH("ctn_pw_wgrad_x6/reduce");
     return CTN_OK;
 }

@@ -475,7 +475,7 @@ def tcn_gln_infer(x0, K, dilations, causal, params):
     h1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
     d = torch.empty((M, H, Kp), dtype=F32, device=dev)
     ms = torch.empty((2, M, 2), dtype=F32, device=dev)
-    nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp)
+    nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp, nb)
     ws = _workspace(nbytes, dev, "tcn_fwd")
     dil = (ctypes.c_int * nb)(*dilations)
     lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1), _p(d), _p(ms), 0,
@@ -502,7 +502,7 @@ class TcnGln(torch.autograd.Function):
         h1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
         ds = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
         ms = torch.empty((nb, 2, M, 2), dtype=F32, device=dev)
-        nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp)
+        nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp, nb)
         ws = _workspace(nbytes, dev, "tcn_fwd")
         dil = (ctypes.c_int * nb)(*dilations)
         lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms), 1,

@@ -45,8 +45,9 @@ int ctn_stream_order(void* from, void* to);
  * convolution_backward for the same layers. */
 
 /* Out[m] = op(W) . f(X[m])  (+ residual[m]),   X:[M,Cn,Kp]  Out:[M,R,Kp]
- *   trans_w = 0: W is [R,Cn] (forward);  trans_w = 1: W is [Cn,R] (input gradient).
- *   pro_part != NULL (trans_w = 0 only): f(x)[i,k] = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i]
+ *   trans_w = 0: W is [R,Cn] (forward);  trans_w = 1: W is [Cn,R] (input gradient, or forward on a transposed copy:
+ *     the fast form -- ctn_transpose_batch).
+ *   pro_part != NULL: f(x)[i,k] = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i]
  *     for k < K, 0 otherwise; (mean_m, rstd_m) are finalised from the [M, pro_nparts, 2] fp64
  *     (sum, sum of squares) partials of prelu(x) -- global LayerNorm, src/conv_tasnet.py:358-360 --
  *     and written to pro_ms_out [M,2] when that is non-NULL.
@@ -61,6 +62,11 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
 int ctn_pw_stats_parts(int M, int R, int Kp);
 /* experiment / autotune hook: force GEMM tile id 0..4 (128x128, 128x64, 64x128, 64x64, 128x64 4x1 waves); -1 = heuristic */
 int ctn_tune_pw_tile(int id);
+
+/* dst[i] = src[i]^T for n equally shaped [rows, cols] fp32 matrices (HOST arrays of device pointers): the forward pass
+ * keeps a [I, O] copy of every 1x1 weight [O, I] so that ctn_pw_gemm(trans_w = 1) -- 16-byte row writes into LDS, no
+ * transposing scatter -- serves forward and input gradient alike (src/conv_tasnet.py:223,262). */
+int ctn_transpose_batch(const void* const* src, void* const* dst, int n, int rows, int cols, void* stream);
 
 /* dN[m] = W^T . dOut[m]   (W:[Cn,R] as stored by the forward layer, dOut:[M,Cn,Kp], dN:[M,R,Kp])
  * and, fused, the two sums gLN backward needs per utterance, as partials
@@ -79,6 +85,10 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
 /* experiment / autotune hook: output tile (0 = heuristic, 64, 128 square, 12864 = 128 x 64) and target workgroups per launch (default 512);
  * call before sizing workspaces */
 int ctn_tune_wgrad(int tile, int blocks);
+/* experiment hook for in-process A/B measurements: key in {"pk", "pk_wgs", "wgrad_kernel", "wgrad_blocks"} (the switches the
+ * CTN_PW_KERNEL / CTN_PK_WGS / CTN_WGRAD_KERNEL / CTN_WGRAD_BLOCKS environment variables set at first use).  Change them
+ * only between steps (workspace sizes and statistics layouts depend on them). */
+int ctn_tune(const char* key, int value);
 
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
@@ -142,7 +152,7 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
                     float* xs, float* h1s, float* ds, float* ms, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream);
-size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp);
+size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp, int nblocks);
 int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
                     const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
                     const float* dout, float* dxs, float* dn1s,

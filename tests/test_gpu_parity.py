@@ -631,3 +631,56 @@ def test_stream_order_entry_point():
         s2.synchronize()
         assert float(y.min()) == float(y.max()) == 20.0 * (it + 1)
         ctn.lib.call("ctn_stream_order", s2.cuda_stream, s1.cuda_stream)
+
+
+# ----------------------------------------------------------------------------- persistent GEMM family (CTN_PW_KERNEL=2)
+@pytest.fixture
+def persistent_gemms():
+    """Select the persistent fp32-MFMA kernels (pw_gemm_pk_kernel) for one test, the default family afterwards."""
+    ctn.lib.call("ctn_tune", b"pk", 1)
+    yield
+    ctn.lib.call("ctn_tune", b"pk", 0)
+    ops._ws_cache.clear()
+
+
+def test_persistent_gemm_family_matches_fp64(persistent_gemms):
+    """Every form of the persistent kernel -- stored and transposed weights, odd k-tile counts, row-overhanging tiles,
+    ReLU / residual / statistics epilogues, gLN prologue, gLN-backward sums -- against fp64 torch."""
+    for (M, R, Cn, K) in [(1, 128, 16, 64), (2, 32, 64, 799), (3, 132, 20, 130), (2, 256, 512, 515), (2, 512, 256, 1000)]:
+        for trans in (False, True):
+            test_pw_gemm_plain(M, R, Cn, K, trans)
+    test_pw_gemm_asymmetric_identity()
+    test_pw_gemm_relu_and_stats_and_prologue()
+    # forward forms on a transposed weight copy (the fast operand form), R = 40 overhangs the 64-row tile
+    M, B, H, K = 3, 24, 40, 1203
+    Kp = ops.padded_frames(K)
+    x = pad(torch.randn(M, B, K, generator=g(4)), Kp).to(DEV)
+    w1 = torch.randn(H, B, generator=g(5)) * 0.2
+    a1 = torch.tensor([0.3])
+    h1, st = ops.pw_gemm(w1.t().contiguous().to(DEV), x, H, B, K, trans_w=True, epi_alpha=a1.to(DEV))
+    ref = torch.einsum("oi,mik->mok", w1.double(), x.double().cpu())
+    assert rel_err(h1, ref) < 3e-6
+    p = O.prelu(ref[..., :K], a1.double())
+    s = st.sum(1).cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), p.sum((1, 2)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (p ** 2).sum((1, 2)).numpy(), rtol=1e-5)
+    g1 = torch.randn(1, H, 1, generator=g(6))
+    b1 = torch.randn(1, H, 1, generator=g(7))
+    w2 = torch.randn(B, H, generator=g(8)) * 0.2
+    ms = torch.empty(M, 2, device=DEV)
+    out2, _ = ops.pw_gemm(w2.t().contiguous().to(DEV), h1, B, H, K, trans_w=True,
+                          pro=(st, g1.to(DEV), b1.to(DEV), a1.to(DEV)), residual=x, ms_out=ms)
+    ref2 = torch.einsum("oi,mik->mok", w2.double(), O.gln(p, g1.double(), b1.double())) + x[..., :K].double().cpu()
+    assert rel_err(out2[..., :K], ref2) < 5e-6
+    assert float(out2[..., K:].abs().max()) == 0.0
+    np.testing.assert_allclose(ms[:, 0].cpu().numpy(), p.mean((1, 2)).numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("norm_type,causal,dil_x,K", [("gLN", False, 3, 799), ("gLN", True, 7, 1203), ("cLN", True, 2, 3700)])
+def test_temporal_block_on_persistent_gemms(persistent_gemms, norm_type, causal, dil_x, K):
+    test_temporal_block_fwd_bwd(norm_type, causal, dil_x, K)
+
+
+def test_tiny_model_on_persistent_gemms(persistent_gemms):
+    """Whole model (composite stack: transposed weight copies + persistent kernels) against the reference fixture."""
+    test_model_matches_reference_golden("model_tiny_gln")
