@@ -123,6 +123,20 @@ def _read_manifest(json_dir, name):
         return json.load(f)
 
 
+def shard_plan(plan, rank, world, equal_counts):
+    """This rank's minibatches of a planned epoch: plan[rank::world].
+
+    equal_counts (training): every step ends in a gradient all-reduce, so all ranks must run the SAME number of steps --
+    the remainder len(plan) % world is dropped (at most world - 1 minibatches per epoch; the reference's single process
+    has no such constraint, src/data.py:82-113).  Ragged minibatch SIZES stay exact: the Solver weights each rank's
+    gradient by its share of the global minibatch.  Validation minibatches have no per-step collective and keep all."""
+    if world <= 1:
+        return plan
+    if equal_counts:
+        plan = plan[: len(plan) // world * world]
+    return plan[rank::world]
+
+
 # ----------------------------------------------------------------------------------------------------
 # datasets / loaders
 # ----------------------------------------------------------------------------------------------------
@@ -142,7 +156,7 @@ class AudioDataset(data.Dataset):
         else:
             self.segment_len = -1
             plan = plan_full_utterance_minibatches(lengths, batch_size, sample_rate, cv_maxlen, max_hours)
-        self.plan = plan[rank::world] if world > 1 else plan
+        self.plan = shard_plan(plan, rank, world, equal_counts=segment >= 0.0)
 
     def __len__(self):
         return len(self.plan)

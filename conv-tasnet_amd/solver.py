@@ -12,6 +12,12 @@ Underneath, one step (:188-196) is: HIP forward -> HIP PIT loss -> HIP backward 
 flat gradient when torch.distributed is initialised] -> fused clip + Adam kernel (FlatAdam) or, for any other
 torch optimiser, clip_grad_norm_ + optimizer.step().  The model may be bare or anything exposing ``.module``.
 visdom is optional and only imported when one of the visdom flags is set.
+
+Data parallel (one process per GPU) keeps the reference's single-decision semantics of nn.DataParallel
+(src/train.py:83-85 + src/solver.py:103-133): every step's loss is the mean over the GLOBAL minibatch (each rank's
+gradient is weighted by its share of the utterances, so ragged shards are exact), the epoch train / validation losses
+are all-reduced before the LR-halving / early-stop / best-model logic, so every rank takes the same decision at the same
+epoch (no replica drift, no rank left alone in a collective), and only rank 0 prints and saves.
 """
 import collections
 import os
@@ -95,8 +101,8 @@ class Solver(object):
     def _reset(self):
         self.start_epoch = 0
         if self.continue_from:
-            print('Loading checkpoint model %s' % self.continue_from)
-            pkg = torch.load(self.continue_from, map_location='cpu', weights_only=False)
+            self._say('Loading checkpoint model %s' % self.continue_from)
+            pkg = torch.load(self.continue_from, map_location='cpu', weights_only=True)   # tensors / numbers / strings only
             self.net.load_state_dict(pkg['state_dict'])
             self.optimizer.load_state_dict(pkg['optim_dict'])
             self.start_epoch = int(pkg.get('epoch', 1))
@@ -124,11 +130,15 @@ class Solver(object):
             net = self.net
             torch.save(net.serialize(net, self.optimizer, epoch, tr_loss=self.tr_loss, cv_loss=self.cv_loss), path)
 
+    def _say(self, msg):
+        if self._rank0:
+            print(msg, flush=True)
+
     def _halve_lr(self):
         sd = self.optimizer.state_dict()            # round trip through state_dict, like the reference
         sd['param_groups'][0]['lr'] = sd['param_groups'][0]['lr'] / 2.0
         self.optimizer.load_state_dict(sd)
-        print('Learning rate adjusted to: %.6f' % sd['param_groups'][0]['lr'])
+        self._say('Learning rate adjusted to: %.6f' % sd['param_groups'][0]['lr'])
 
     # -- the loop -------------------------------------------------------------------------------------
     def train(self):
@@ -137,21 +147,21 @@ class Solver(object):
             t0 = time.time()
             self.model.train()
             tr = self._run_one_epoch(epoch)
-            print('%s\nTrain Summary | End of Epoch %d | Time %.2fs | Train Loss %.3f\n%s'
-                  % (bar, epoch + 1, time.time() - t0, tr, bar))
+            self._say('%s\nTrain Summary | End of Epoch %d | Time %.2fs | Train Loss %.3f\n%s'
+                      % (bar, epoch + 1, time.time() - t0, tr, bar))
             if self.enable_checkpoint:
                 path = os.path.join(self.save_folder, "checkpoint_models", 'epoch%d.pth.tar' % (epoch + 1))
                 self._save(path, epoch + 1)
-                print('Saving checkpoint model to %s' % path)
+                self._say('Saving checkpoint model to %s' % path)
 
             self.model.eval()
             cv = self._run_one_epoch(epoch, cross_valid=True)
-            print('%s\nValid Summary | End of Epoch %d | Time %.2fs | Valid Loss %.3f\n%s'
-                  % (bar, epoch + 1, time.time() - t0, cv, bar))
+            self._say('%s\nValid Summary | End of Epoch %d | Time %.2fs | Valid Loss %.3f\n%s'
+                      % (bar, epoch + 1, time.time() - t0, cv, bar))
 
             halve, stop = self.schedule.update(cv)
             if stop:
-                print("No improvement for 7 epochs, early stopping.")
+                self._say("No improvement for 7 epochs, early stopping.")
                 break
             if halve:
                 self._halve_lr()
@@ -161,9 +171,21 @@ class Solver(object):
                 self.best_val_loss = cv
                 path = os.path.join(self.save_folder, self.model_path)
                 self._save(path, epoch + 1)
-                print("Found better validated model, saving to %s" % path)
+                self._say("Found better validated model, saving to %s" % path)
             if self._plot is not None and self.visdom_enabled:
                 self._plot(epoch)
+
+    def _global_loss(self, loss, n_local):
+        """(loss to back-propagate, loss to report) of the GLOBAL minibatch: with world ranks the reported loss is
+        sum_r n_r loss_r / sum_r n_r, and the back-propagated one is scaled so that the 1/world average of the gradient
+        all-reduce reproduces exactly that mean (n_r = utterances on rank r; equal shards -> scale 1)."""
+        world = parallel.world_size()
+        if world == 1:
+            return loss, loss
+        import torch.distributed as dist
+        t = torch.stack((loss.detach() * n_local, loss.detach().new_tensor(float(n_local))))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return loss * (n_local * world / t[1]), t[0] / t[1]
 
     def _optimise(self, loss):
         """zero_grad -> backward -> (all-reduce) -> clip -> step."""
@@ -181,18 +203,30 @@ class Solver(object):
     def _run_one_epoch(self, epoch, cross_valid=False):
         loader = self.cv_loader if cross_valid else self.tr_loader
         dev = next(self.model.parameters()).device
+        world = parallel.world_size()
         t0, running, n = time.time(), 0.0, 0
         for mixture, lengths, sources in loader:
             mixture, lengths, sources = mixture.to(dev), lengths.to(dev), sources.to(dev)
             with torch.set_grad_enabled(not cross_valid):
                 loss = cal_loss(sources, self.model(mixture), lengths)[0]
             if not cross_valid:
+                # training steps are collective (equal step counts per rank: data.AudioDataset equalises the plan)
+                loss, report = self._global_loss(loss, int(mixture.shape[0]))
                 self._optimise(loss)
-            value = loss.item()
+            else:
+                report = loss
+            value = report.item()
             self.iter_losses.append(value)
             running += value
-            if n % self.print_freq == 0:
+            if n % self.print_freq == 0 and self._rank0:
                 print('Epoch %d | Iter %d | Average Loss %.3f | Current Loss %.6f | %.1f ms/batch'
                       % (epoch + 1, n + 1, running / (n + 1), value, 1000 * (time.time() - t0) / (n + 1)), flush=True)
             n += 1
+        if cross_valid and world > 1:
+            # validation minibatches are dealt to the ranks (any counts): sum and count over ALL of them give the number the
+            # single-process reference computes, and every rank gets the same value for the schedule
+            import torch.distributed as dist
+            t = torch.tensor([running, float(n)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            running, n = float(t[0]), int(round(float(t[1])))
         return running / (n + 1)        # (n_batches + 1): the reference's divisor, kept for trajectory parity

@@ -22,3 +22,46 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+# ---- data-parallel GPU test: children are started before anything in this process touches the GPU -------------------
+_DP = {}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def pytest_collection_finish(session):
+    """Spawn tests/dp_worker.py (2 ranks + the single-process reference) if the DP GPU test was selected and a GPU exists.
+    torch.cuda.device_count() does not initialise the GPU; the children run beside the other tests and are collected by
+    tests/test_dp_gpu.py."""
+    if not any(it.nodeid.endswith("test_two_rank_product_training_matches_single_process") for it in session.items):
+        return
+    import subprocess
+    import tempfile
+    import torch
+    if torch.cuda.device_count() < 1:
+        return
+    tmp = tempfile.mkdtemp(prefix="ctn_dp_")
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    procs, outs, logs = {}, {}, {}
+    port2, port1 = _free_port(), _free_port()
+    for name, rank, world, port in (("rank0", 0, 2, port2), ("rank1", 1, 2, port2), ("single", 0, 1, port1)):
+        outs[name] = os.path.join(tmp, name + ".pt")
+        logs[name] = os.path.join(tmp, name + ".log")
+        procs[name] = subprocess.Popen([sys.executable, worker, str(rank), str(world), port, outs[name]],
+                                       stdout=open(logs[name], "w"), stderr=subprocess.STDOUT, cwd=ROOT)
+    _DP["children"] = (procs, outs, logs)
+
+
+@pytest.fixture
+def dp_children():
+    if "children" not in _DP:
+        pytest.skip("no GPU visible at collection time: the data-parallel children were not started")
+    return _DP["children"]

@@ -58,11 +58,21 @@ def test_segment_rule():
 
 
 def test_rank_sharding_partitions_the_plan(manifest):
+    """Training plans: disjoint shards with EQUAL step counts (every step ends in a collective; the remainder of
+    len(plan) % world minibatches is dropped).  Validation plans (segment < 0): every minibatch kept, counts may differ."""
     g, jdir = manifest
-    full = D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader).plan
-    parts = [D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader, rank=r, world=2).plan for r in range(2)]
-    assert sorted(map(tuple, parts[0] + parts[1])) == sorted(map(tuple, full))
-    assert not set(map(tuple, parts[0])) & set(map(tuple, parts[1]))
+    for world in (2, 3):
+        full = D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader).plan
+        parts = [D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader, rank=r, world=world).plan
+                 for r in range(world)]
+        assert len(set(len(p) for p in parts)) == 1 and len(parts[0]) == len(full) // world
+        kept = full[: len(full) // world * world]
+        assert sorted(map(tuple, sum(parts, []))) == sorted(map(tuple, kept))
+        assert sum(len(set(map(tuple, p))) for p in parts) == len(set(map(tuple, kept)))
+        cv_full = D.AudioDataset(jdir, batch_size=1, segment=-1, cv_maxlen=100, reader=synth_reader).plan
+        cv_parts = [D.AudioDataset(jdir, batch_size=1, segment=-1, cv_maxlen=100, reader=synth_reader, rank=r, world=world).plan
+                    for r in range(world)]
+        assert sorted(map(tuple, sum(cv_parts, []))) == sorted(map(tuple, cv_full))
 
 
 def test_eval_dataset_and_wav_reader(tmp_path):

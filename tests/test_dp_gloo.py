@@ -71,3 +71,33 @@ def test_shard_batch_rejects_ragged_split():
         parallel.shard_batch((torch.zeros(5, 3),), rank=0, world=2)
     a, = parallel.shard_batch((torch.arange(8).view(8, 1),), rank=1, world=4)
     assert a.flatten().tolist() == [2, 3]
+
+
+def _loss_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from conv_tasnet_amd import parallel
+    from conv_tasnet_amd.solver import Solver
+    parallel.init_distributed(backend="gloo")
+    n_local = (5, 3)[rank]
+    x = torch.tensor([1.0 + rank], requires_grad=True)
+    loss = (x * x).sum() * (2.0 + rank)                   # rank 0: 2, rank 1: 12
+    back, report = Solver._global_loss(None, loss, n_local)
+    back.backward()
+    torch.save({"report": float(report), "grad": float(x.grad), "dloss": float((2.0 + rank) * 2 * (1.0 + rank))},
+               os.path.join(out_dir, "l%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_minibatch_loss_weights_ragged_shards(tmp_path):
+    """Solver._global_loss: the reported loss is the utterance-weighted mean over ranks, and the back-propagated loss is
+    scaled so that the 1/world average of the gradient all-reduce equals the gradient of that mean."""
+    world, port = 2, _free_port()
+    mp.spawn(_loss_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / ("l%d.pt" % k)) for k in range(2)]
+    assert r[0]["report"] == r[1]["report"] and abs(r[0]["report"] - (5 * 2.0 + 3 * 12.0) / 8) < 1e-6
+    # (1/world) * sum_r scale_r dloss_r/dx_r  ==  d/dx of the weighted mean:  scale_r = n_r * world / n
+    for k, n in enumerate((5, 3)):
+        assert abs(r[k]["grad"] - r[k]["dloss"] * n * 2 / 8) < 1e-6
