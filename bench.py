@@ -1,18 +1,26 @@
 #!/usr/bin/env python
 """Conv-TasNet training-step throughput on MI355X (BASELINE.json metric: 4 s / 8 kHz / 2-spk utterances per second, fwd+bwd).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config paper|causal|c3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one synthetic minibatch resident in HBM: forward, PIT SI-SNR loss, backward,
 (N>1: one RCCL all-reduce of the flat gradient), clip_grad_norm(5) + Adam -- the step of src/solver.py:188-196.
-Workload: BASELINE configs[1], paper config N256 L20 B256 H512 P3 X8 R4 gLN C2, 8 utterances of 4 s @ 8 kHz per GPU
-(weak scaling: global batch = 8 * N).  Rank 0 prints ONE JSON line.
+Default workload: BASELINE configs[1], paper config N256 L20 B256 H512 P3 X8 R4 gLN C2, 8 utterances of 4 s @ 8 kHz per
+GPU (weak scaling: global batch = 8 * N).  --config causal = configs[3] (cLN, causal), --config c3 = configs[4]
+(3 speakers, L=16, 16 kHz).  Rank 0 prints ONE JSON line.
+
+`roofline` (rank 0): after the timed region a few more training steps run with a HIP-event pair around EVERY launch
+group of the block kernels (the per-kernel entry points driven from Python: the same kernels in the same order as the
+composite C calls of the timed region, each bracketed on the stream it is launched on).  The line reports the family
+with the largest total time (`roofline.kernel`) and the whole table (`roofline.families`).  `cpu_baseline` (rank 0):
+the oracle's training step on the host cores, bounded in wall time.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -21,10 +29,18 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PAPER = dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2)
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)" (154.5 measured on the box:
+                               # benchmarks/mfma_probe.hip, profiles/r02_a_mfma_probe.txt)
+PEAK_HBM_GBS = 8000.0          # same guide, HBM3E peak
 PER_GPU_BATCH = 8
-T_SAMPLES = 32000
+CONFIGS = {
+    "paper": dict(model=dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2), norm_type="gLN", causal=False, T=32000, sr=8000,
+                  name="BASELINE configs[1]: paper config N256 L20 B256 H512 P3 X8 R4 gLN non-causal C2, %d x 4s@8kHz"),
+    "causal": dict(model=dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2), norm_type="cLN", causal=True, T=32000, sr=8000,
+                   name="BASELINE configs[3]: causal cLN variant N256 L20 B256 H512 P3 X8 R4 C2, %d x 4s@8kHz"),
+    "c3": dict(model=dict(N=256, L=16, B=256, H=512, P=3, X=8, R=4, C=3), norm_type="gLN", causal=False, T=64000, sr=16000,
+               name="BASELINE configs[4]: 3-speaker C3 L16 N256 B256 H512 P3 X8 R4 gLN, %d x 4s@16kHz"),
+}
 
 
 def flops_fwd(c, T):
@@ -34,69 +50,169 @@ def flops_fwd(c, T):
                     + c["B"] * c["C"] * c["N"] + c["C"] * c["N"] * c["L"]), K
 
 
-def cpu_baseline(max_seconds=30.0):
-    """The oracle (torch CPU restatement of the reference step) on this host's cores: bounded sample."""
-    from oracle import ctn_oracle as O
-    cfg = O.Config(**PAPER)
-    torch.set_num_threads(min(16, torch.get_num_threads()))     # the 1-GPU box's CPU share
-    threads = torch.get_num_threads()
-    sd = O.init_params(cfg, seed=0)
-    state = {}
-    mix, lens, src = O.synth_batch(0, 1, T_SAMPLES)
-    O.train_step(cfg, sd, state, mix, src, lens)            # warm-up (allocator, thread pool)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.train_step(cfg, sd, state, mix, src, lens)
-        n += 1
-        dt = time.perf_counter() - t0
-        if n >= 3 or dt > max_seconds:
+# ---------------------------------------------------------------------------------------------------------------------
+# cpu_baseline: BASELINE.md section 4
+# ---------------------------------------------------------------------------------------------------------------------
+def _host_cpu():
+    """(model string, cores this process may really use, how that was found): physical cores of /proc/cpuinfo, capped by
+    the affinity mask and by the cgroup CPU quota (a 1-GPU box of the pool gets a share of its host's cores: running one
+    thread per physical core of the HOST on that share is slower than the share -- measured 77 s vs 25 s per step)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    limits = {"physical_cores": len(cores) or (os.cpu_count() or 1)}
+    if hasattr(os, "sched_getaffinity"):
+        limits["affinity"] = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    limits["cgroup_quota"] = max(1, int(int(txt[0]) / int(txt[1])))
+            elif int(txt[0]) > 0:
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                limits["cgroup_quota"] = max(1, int(int(txt[0]) / period))
             break
-    return {"value": round(n / dt, 4), "unit": "utterances/sec", "cores": threads, "kind": "port",
-            "sample": "%d full training steps (fwd+loss+bwd+clip+Adam) of the paper config on 1 utterance of 4 s, "
-                      "oracle/ctn_oracle.py with torch CPU ops, %d threads, after 1 warm-up step" % (n, threads)}
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("CTN_CPU_BASELINE_THREADS")
+    if env:
+        limits["CTN_CPU_BASELINE_THREADS"] = int(env)
+    n = min(limits.values())
+    return model, max(n, 1), ", ".join("%s=%d" % kv for kv in limits.items())
 
 
-def dominant_kernel_roofline(ctn, device, K, iters=30, in_step_us=None, in_step_n=0, in_step_steps=0):
-    """Time the dominant kernel (the 1x1-conv fp32-MFMA GEMM, B->H with the fused PReLU/gLN-statistics epilogue)
-    at the workload's shape with HIP events on the stream it is launched on."""
-    from conv_tasnet_amd import ops
-    M, B, H = PER_GPU_BATCH, PAPER["B"], PAPER["H"]
-    Kp = ops.padded_frames(K)
-    x = torch.randn(M, B, Kp, device=device)
-    x[..., K:] = 0
-    W = torch.randn(H, B, device=device) * 0.05
-    a = torch.full((1,), 0.25, device=device)
-    for _ in range(3):
-        ops.pw_gemm(W, x, H, B, K, epi_alpha=a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()                      # torch's current stream == the stream ops._stream() hands to the C ABI
-    for _ in range(iters):
-        ops.pw_gemm(W, x, H, B, K, epi_alpha=a)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flop = 2.0 * H * B * M * K       # algorithmic: 2*H*B per frame, K frames per utterance, M utterances per launch
-    ach = flop / (ms * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+def cpu_baseline(cfg, budget_s=40.0):
+    """The oracle (torch CPU restatement of the reference step: fwd + loss + bwd + clip(5) + Adam) on this host, batch 8,
+    all physical cores this process may use; then the same on 8 threads (the survey container's count).  Bounded in wall
+    time, not in sample: up to 3 warm-up + 10 timed steps inside the budget (a step of the paper config takes seconds)."""
+    from oracle import ctn_oracle as O
+    ocfg = O.Config(norm_type=cfg["norm_type"], causal=cfg["causal"], **cfg["model"])
+    model, cores, how = _host_cpu()
+    mix, lens, src = O.synth_batch(0, PER_GPU_BATCH, cfg["T"], C=cfg["model"]["C"], sr=cfg["sr"])
+
+    def run(threads, budget, max_warm, max_steps):
+        torch.set_num_threads(threads)
+        sd, state = O.init_params(ocfg, seed=0), {}
+        t_start, times, warm = time.perf_counter(), [], 0
+        while True:
+            t0 = time.perf_counter()
+            O.train_step(ocfg, sd, state, mix, src, lens)
+            dt = time.perf_counter() - t0
+            elapsed = time.perf_counter() - t_start
+            if warm < max_warm and (warm == 0 or elapsed + 2 * dt < budget * 0.35):
+                warm += 1                      # the first call always is a warm-up (allocator, thread pool)
+            else:
+                times.append(dt)
+            if len(times) >= max_steps or (times and elapsed + dt > budget):
+                return warm, times
+
+    warm, times = run(cores, budget_s, 3, 10)
+    med, best = statistics.median(times), min(times)
+    out = {"value": round(PER_GPU_BATCH / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
+           "cpu_model": model, "cores_from": how, "batch": PER_GPU_BATCH, "warmup_steps": warm, "timed_steps": len(times),
+           "median_s_per_step": round(med, 3), "min_s_per_step": round(best, 3),
+           "value_at_min": round(PER_GPU_BATCH / best, 4),
+           "sample": "%d timed full training steps (fwd+PIT loss+bwd+clip(5)+Adam) of the workload's config on its batch of "
+                     "%d utterances after %d warm-up step(s), oracle/ctn_oracle.py with torch CPU ops on %d threads (every "
+                     "core usable by the process: min of physical cores, affinity mask, cgroup quota), wall budget %.0f s; "
+                     "value = batch / median step time"
+                     % (len(times), PER_GPU_BATCH, warm, cores, budget_s)}
+    if cores != 8:
+        w8, t8 = run(min(8, cores), budget_s * 0.4, 1, 3)
+        out["threads8"] = {"value": round(PER_GPU_BATCH / statistics.median(t8), 4), "timed_steps": len(t8), "warmup_steps": w8,
+                           "threads": min(8, cores)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline: per-family in-step timing of the block kernels
+# ---------------------------------------------------------------------------------------------------------------------
+def _family(name, a):
+    """Classify one probed lib.call (entry point + arguments, include/ctn_hip.h) into a kernel family of DESIGN.md."""
+    if name == "ctn_pw_gemm":
+        M, R, Cn, trans_w, pro, residual, epi_part, relu = a[3], a[4], a[5], a[8], a[9], a[15], a[17], a[18]
+        shape = (M, R, Cn)
+        if pro:
+            return "K3 pw_gemm<PRO_PRELU_NORM,EPI_RESIDUAL> (1x1 H->B, gLN prologue + residual)", "mfma", shape
+        if epi_part:
+            return "K1 pw_gemm<EPI_PRELU_STATS> (1x1 B->H + PReLU/gLN statistics)", "mfma", shape
+        if trans_w and residual:
+            return "B5 pw_gemm<T,EPI_RESIDUAL> (input gradient W1^T.dh1 + dout)", "mfma", shape
+        return "pw_gemm plain (encoder / bottleneck / mask / decoder, fwd or dgrad)", "mfma", shape
+    if name == "ctn_pw_dgrad_gln":
+        return "B1 pw_gemm<T,EPI_GLN_BWD> (input gradient W2^T.dout + gLN backward sums)", "mfma", (a[3], a[4], a[5])
+    if name == "ctn_pw_wgrad":
+        fam = "B2 pw_wgrad<PRO> + slab_reduce (dW2)" if a[11] else "B6 pw_wgrad + slab_reduce (dW1 and the small layers)"
+        return fam, "mfma", (a[3], a[4], a[5])
+    return {"ctn_dw_fwd": "K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)",
+            "ctn_dw_bwd": "B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)",
+            "ctn_gln_prelu_bwd": "B4 gln_prelu_bwd",
+            "ctn_dw_bwd_finalize": "dw_bwd_finalize (fixed-order parameter-gradient sums)"}.get(name, name), "hbm", None
+
+
+def family_table(probe, cfg, K, steps):
+    c = cfg["model"]
+    M, H = PER_GPU_BATCH, c["H"]
+    hbm_bytes = {"ctn_dw_fwd": 2, "ctn_dw_bwd": 4, "ctn_gln_prelu_bwd": 3}      # tensors of M*H*K*4 bytes read + written
+    fams = {}
+    for name, a, e0, e1 in probe:
+        fam, bound, shape = _family(name, a)
+        f = fams.setdefault(fam, {"bound": bound, "us": [], "work": 0.0, "entry": name})
+        f["us"].append(1e3 * e0.elapsed_time(e1))
+        if bound == "mfma":
+            f["work"] += 2.0 * shape[1] * shape[2] * K * shape[0]            # algorithmic FLOPs: 2*R*Cn per frame
+        elif name in hbm_bytes:
+            f["work"] += hbm_bytes[name] * 4.0 * M * H * K                   # algorithmic bytes
+    rows = []
+    for fam, f in fams.items():
+        tot = sum(f["us"])
+        row = {"family": fam, "bound": f["bound"], "launches_per_step": round(len(f["us"]) / steps, 1),
+               "us_per_launch": round(tot / len(f["us"]), 2), "ms_per_step": round(tot / steps / 1e3, 3)}
+        if f["work"] > 0:
+            rate = f["work"] / (tot * 1e-6)
+            if f["bound"] == "mfma":
+                row.update(achieved=round(rate / 1e12, 2), unit="TFLOP/s", frac=round(rate / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+            else:
+                row.update(achieved=round(rate / 1e9, 1), unit="GB/s", frac=round(rate / 1e9 / PEAK_HBM_GBS, 4))
+            row["work_per_launch"] = f["work"] / len(f["us"])
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def roofline(rows, probe_steps):
+    dom = rows[0]
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_dominant_kernel.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            j = json.load(open(pmc))
+            if j.get("family", "")[:2] == dom["family"][:2]:
+                traffic, src = j.get("hbm_bytes_per_launch"), "profiles/r02_pmc_dominant_kernel.json"
         except Exception:
-            traffic = None
-    out = {"bound": "mfma", "kernel": "pw_gemm_kernel<0,PRO_NONE,EPI_PRELU_STATS> (1x1 conv B->H, fp32 MFMA)",
-           "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "us_per_launch": round(ms * 1e3, 2),
-           "flop_per_launch": flop, "traffic": traffic, "how": "%d back-to-back launches after the timed steps" % iters}
-    if in_step_us is not None:       # the same kernel measured inside real training steps (one event pair per launch)
-        ach2 = flop / (in_step_us * 1e-6) / 1e12
-        out.update({"achieved": round(ach2, 2), "frac": round(ach2 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "us_per_launch": round(in_step_us, 2), "how": "HIP-event pair around each of the %d launches of this "
-                    "kernel in %d extra training steps after the timed region" % (in_step_n, in_step_steps),
-                    "back_to_back": {"us_per_launch": round(ms * 1e3, 2), "achieved": round(ach, 2),
-                                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches": iters}})
-    return out
+            pass
+    return {"bound": dom["bound"], "kernel": dom["family"], "achieved": dom.get("achieved"),
+            "peak": PEAK_F32_MFMA_TFLOPS if dom["bound"] == "mfma" else PEAK_HBM_GBS, "unit": dom.get("unit"),
+            "frac": dom.get("frac"), "us_per_launch": dom["us_per_launch"], "launches_per_step": dom["launches_per_step"],
+            "work_per_launch": dom.get("work_per_launch"), "traffic": traffic, "traffic_source": src,
+            "how": "largest total time among the kernel families of %d extra training steps after the timed region, each "
+                   "launch group bracketed by a HIP-event pair on the stream it is launched on (weight-gradient groups run "
+                   "on the second stream and overlap the chain, so in-step durations include that sharing)" % probe_steps,
+            "families": rows}
 
 
 def main():
@@ -104,22 +220,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="paper")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CTN_BENCH_GRAPH", "0")),
                     help="1: replay zero_grad+fwd+loss+bwd from one captured HIP graph (conv_tasnet_amd.graphed)")
-    ap.add_argument("--gemm", choices=["fp32", "x6"], default=None,
-                    help="1x1-conv arithmetic: fp32 MFMA (default, bit-exact fp32 chains) or split-bf16 emulation (experimental)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch.distributed as dist
     import conv_tasnet_amd as ctn
-    from conv_tasnet_amd import parallel
+    from conv_tasnet_amd import ops, parallel
     from conv_tasnet_amd.optim import FlatAdam
     from conv_tasnet_amd.train import SyntheticLoader   # synthetic workload of SURVEY 8d (product code, not the oracle)
 
-    if args.gemm:
-        from conv_tasnet_amd import ops as _ops
-        _ops.set_gemm_mode(args.gemm)
     world, rank, device = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
@@ -127,11 +241,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     torch.manual_seed(0)
-    model = ctn.ConvTasNet(**PAPER, norm_type="gLN", causal=False, mask_nonlinear="relu").to(device)
+    model = ctn.ConvTasNet(**cfg["model"], norm_type=cfg["norm_type"], causal=cfg["causal"], mask_nonlinear="relu").to(device)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     parallel.broadcast_parameters(opt.flat_params)
     # this rank's shard: utterances [rank*8, rank*8+8) of the deterministic harmonic-mixture workload
-    mix, lens, src = next(iter(SyntheticLoader(1, PER_GPU_BATCH, samples=T_SAMPLES, rank=rank, world=world)))
+    mix, lens, src = next(iter(SyntheticLoader(1, PER_GPU_BATCH, samples=cfg["T"], C=cfg["model"]["C"], sample_rate=cfg["sr"],
+                                               rank=rank, world=world)))
     mix, lens, src = mix.to(device), lens.to(device), src.to(device)
     loss_acc = torch.zeros((), device=device)
 
@@ -158,10 +273,12 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    issue = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ti = time.perf_counter()
         step()
-    t_issue = time.perf_counter() - t0          # host time to enqueue the timed steps (diagnostic only)
+        issue.append(time.perf_counter() - ti)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -173,38 +290,41 @@ def main():
     mean_loss = float(loss_acc) / max(args.steps, 1)
 
     if rank == 0:
-        ffwd, K = flops_fwd(PAPER, T_SAMPLES)
-        ftrain = 3 * ffwd - 4 * K * PAPER["N"] * PAPER["L"]
+        ffwd, K = flops_fwd(cfg["model"], cfg["T"])
+        ftrain = 3 * ffwd - 4 * K * cfg["model"]["N"] * cfg["model"]["L"]
         utt = PER_GPU_BATCH * world * args.steps
         value = utt / dt
         out = {
             "metric": "4s 8kHz 2-spk utterances/sec (fwd+bwd)", "value": round(value, 2), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: paper config N256 L20 B256 H512 P3 X8 R4 gLN non-causal C2, "
-                                   "%d x 4s@8kHz utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam" % PER_GPU_BATCH,
-                       "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": T_SAMPLES,
+            "config": {"workload": (cfg["name"] % PER_GPU_BATCH) + " utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam",
+                       "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": cfg["T"],
                        "parallelism": "dp%d" % world},
-            "gemm_mode": __import__("conv_tasnet_amd").ops.gemm_mode(), "hip_graph": bool(args.graph),
-            "mean_loss": round(mean_loss, 4), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
+            "hip_graph": bool(args.graph), "mean_loss": round(mean_loss, 4),
+            # host time to enqueue one step, measured while the queues have room (the median: late steps of a long run
+            # block on queue back-pressure, which is GPU time, not host work)
+            "host_issue_ms_per_step": round(1e3 * statistics.median(issue[: max(3, len(issue) // 2)]), 3),
             "model_tflops": round(value * ftrain / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }
-        if world == 1:
-            # the dominant kernel inside real steps: a few extra steps with an event pair around each of its launches
-            from conv_tasnet_amd import ops as _o
-            probe, probe_steps = [], 3
-            _o.set_stats_gemm_probe(probe)
-            for _ in range(probe_steps):
-                step()
-            _o.set_stats_gemm_probe(None)
-            torch.cuda.synchronize()
-            M_, B_, H_ = PER_GPU_BATCH, PAPER["B"], PAPER["H"]
-            us = [1e3 * e0.elapsed_time(e1) for e0, e1, m, r, cn, k in probe if (m, r, cn) == (M_, H_, B_)]
-            in_us = sum(us) / len(us) if us else None
-            out["roofline"] = dominant_kernel_roofline(ctn, device, K, in_step_us=in_us, in_step_n=len(us), in_step_steps=probe_steps)
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
+    if not args.no_roofline and graphed is None:
+        # every rank takes part (the steps contain the gradient all-reduce); rank 0 keeps the table
+        probe_steps, was = 3, ops._COMPOSITE
+        ops._COMPOSITE = False                  # per-kernel entry points: the same kernels, individually bracketed
+        step()                                  # settle allocations of the per-kernel path
+        torch.cuda.synchronize()
+        ctn.lib.probe = []
+        for _ in range(probe_steps):
+            step()
+        torch.cuda.synchronize()
+        probe, ctn.lib.probe = ctn.lib.probe, None
+        ops._COMPOSITE = was
+        if rank == 0:
+            out["roofline"] = roofline(family_table(probe, cfg, K, probe_steps), probe_steps)
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

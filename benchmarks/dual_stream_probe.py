@@ -54,6 +54,7 @@ def halves(fwd_only=False):
             losses.append(ctn.cal_loss(src[sl], m(mix[sl]), lens[sl])[0])
     for st, l in zip((s1, s2), losses):
         with torch.cuda.stream(st):
+            opt._written.clear()            # timing probe: the second half overwrites the first half's gradients
             l.backward()
     for st in (s1, s2):
         cur.wait_stream(st)

@@ -52,6 +52,7 @@ class CtnError(RuntimeError):
 class _Lib:
     def __init__(self):
         self._dll = None
+        self.probe = None       # list -> every lib.call is bracketed by two timing events (bench.py's roofline leg)
         self.protos = parse_header()
         if EXPERIMENTAL:
             self.protos.update(parse_header(HEADER_EXPERIMENTAL))
@@ -76,9 +77,21 @@ class _Lib:
 
     def call(self, name, *args):
         """Call an int-status entry point; raise CtnError with the library's message on failure."""
+        if self.probe is not None:              # measurement hook (bench.py): HIP events around this call on its stream
+            return self._probed_call(name, args)
         rc = getattr(self.load(), name)(*args)
         if rc != 0:
             raise CtnError("%s failed (%d): %s" % (name, rc, self._dll.ctn_last_error().decode()))
+
+    def _probed_call(self, name, args):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                             # torch's current stream == the stream every wrapper hands to the C ABI
+        rc = getattr(self.load(), name)(*args)
+        e1.record()
+        if rc != 0:
+            raise CtnError("%s failed (%d): %s" % (name, rc, self._dll.ctn_last_error().decode()))
+        self.probe.append((name, args, e0, e1))
 
 
 lib = _Lib()

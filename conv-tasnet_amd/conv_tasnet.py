@@ -125,9 +125,41 @@ class Decoder(nn.Module):
 
     def forward(self, mixture_w, est_mask):
         M, C, N, K = est_mask.shape
-        sw = _pad_frames(mixture_w.unsqueeze(1) * est_mask, K).view(M * C, N, -1)
+        w = _pad_frames(mixture_w.to(torch.float32), K)
+        mask = _pad_frames(est_mask.to(torch.float32), K).view(M, C * N, -1)
+        sw = _MaskMul.apply(mask, w, C, 2).view(M * C, N, -1)                     # source_w = mixture_w * est_mask (:140)
         T = (K - 1) * (self.L // 2) + self.L
         return _BasisOla.apply(sw, self.basis_signals.weight, K, T).view(M, C, T)
+
+
+class _MaskMul(torch.autograd.Function):
+    """sw [M,C,N,Kp] = w [M,N,Kp] * act(score [M,C*N,Kp]) through ctn_mask_apply; mode 0 relu, 1 softmax over speakers,
+    2 identity.  Columns k >= K of score and w are zeros (so are sw's, except the softmax of a zero score column times
+    w = 0 -- also zero)."""
+
+    @staticmethod
+    def forward(ctx, score, w, C, mode):
+        score, w = score.contiguous(), w.contiguous()
+        M, N, Kp = w.shape
+        sw = torch.empty((M, C, N, Kp), dtype=torch.float32, device=w.device)
+        ops._chk(score, w)
+        ops.lib.call("ctn_mask_apply", score.data_ptr(), w.data_ptr(), sw.data_ptr(), M, C, N, Kp, mode, ops._stream())
+        ctx.save_for_backward(score, w)
+        ctx.cfg = (C, mode)
+        return sw
+
+    @staticmethod
+    def backward(ctx, dsw):
+        score, w = ctx.saved_tensors
+        C, mode = ctx.cfg
+        M, N, Kp = w.shape
+        dsw = dsw.contiguous()
+        dscore = torch.empty_like(score)
+        dw = torch.empty_like(w)
+        ops._chk(dsw)
+        ops.lib.call("ctn_mask_apply_bwd", dsw.data_ptr(), score.data_ptr(), w.data_ptr(), dscore.data_ptr(), dw.data_ptr(),
+                     M, C, N, Kp, mode, ops._stream())
+        return dscore, dw, None, None
 
 
 class _BasisOla(torch.autograd.Function):
@@ -214,10 +246,10 @@ class TemporalConvNet(nn.Module):
         y0 = _ClnOnly.apply(w, ln.gamma, ln.beta, K)
         x = _Pointwise.apply(y0, bn.weight, K)
         x = self.blocks(x, K)
-        score = _Pointwise.apply(x, self.network[3].weight, K)[..., :K].view(M, self.C, N, K)
-        if self.mask_nonlinear == 'softmax':
-            return torch.softmax(score, dim=1)
-        return torch.relu(score)
+        score = _Pointwise.apply(x, self.network[3].weight, K)                     # [M, C*N, Kp]
+        ones = torch.ones((M, N, score.shape[-1]), dtype=torch.float32, device=score.device)
+        mask = _MaskMul.apply(score, ones, self.C, 1 if self.mask_nonlinear == 'softmax' else 0)   # relu | softmax over C
+        return mask[..., :K]
 
 
 class _Pointwise(torch.autograd.Function):
@@ -414,19 +446,49 @@ class ChannelwiseLayerNorm(_NormParams):
         return _ClnOnly.apply(_pad_frames(y, K), self.gamma, self.beta, K)[..., :K]
 
 
+class _GlnOnly(torch.autograd.Function):
+    """Stand-alone gLN with its backward (src/conv_tasnet.py:338-361 is an ordinary autograd module).  Forward: statistics
+    and apply as two passes of the depthwise kernel with a unit tap; backward: ctn_gln_bwd_sums (per-row S1, S2 and the
+    dgamma / dbeta partials) + ctn_gln_prelu_bwd with a PReLU slope of 1 (= identity) + the fixed-order reductions."""
+
+    @staticmethod
+    def forward(ctx, yp, gamma, beta, K):
+        M, Ch, Kp = yp.shape
+        dev = yp.device
+        one_tap = torch.ones((Ch, 1, 1), dtype=torch.float32, device=dev)
+        one = torch.ones((1,), dtype=torch.float32, device=dev)           # PReLU slope 1 = identity
+        ms = torch.empty((M, 2), dtype=torch.float32, device=dev)
+        _, stats = ops.dw_fwd(yp, one_tap, K, 1, False, epi_alpha=one)
+        out, _ = ops.dw_fwd(yp, one_tap, K, 1, False, pro=(stats, gamma, beta, one), ms_out=ms)
+        ctx.save_for_backward(yp, gamma, ms, one)
+        ctx.K = K
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        yp, gamma, ms, one = ctx.saved_tensors
+        K = ctx.K
+        M, Ch, Kp = yp.shape
+        dev = yp.device
+        dout = _pad_zero_tail(dout.contiguous(), K)
+        sums = torch.empty((M, Ch, 2), dtype=torch.float64, device=dev)
+        pc = torch.empty((2, M, Ch), dtype=torch.float32, device=dev)
+        dy = torch.empty_like(yp)
+        dap = torch.empty((M * Ch,), dtype=torch.float32, device=dev)
+        ops._chk(dout, yp, gamma, ms)
+        ops.lib.call("ctn_gln_bwd_sums", dout.data_ptr(), yp.data_ptr(), M, Ch, K, Kp, gamma.data_ptr(), one.data_ptr(),
+                     ms.data_ptr(), sums.data_ptr(), pc.data_ptr(), ops._stream())
+        ops.lib.call("ctn_gln_prelu_bwd", dout.data_ptr(), yp.data_ptr(), dy.data_ptr(), M, Ch, K, Kp, gamma.data_ptr(),
+                     one.data_ptr(), ms.data_ptr(), sums.data_ptr(), Ch, dap.data_ptr(), ops._stream())
+        dgb = ops.reduce_mid(pc, 2, M, Ch)
+        return dy, dgb[0].view_as(gamma), dgb[1].view_as(gamma), None
+
+
 class GlobalLayerNorm(_NormParams):
-    """gLN, src/conv_tasnet.py:338-361.  Inside a TemporalBlock it is fused into the neighbouring kernels; called on
-    its own (inference only) it runs as two passes of the depthwise kernel with a unit tap: statistics, then apply."""
+    """gLN, src/conv_tasnet.py:338-361.  Inside a TemporalBlock it is fused into the neighbouring kernels; called on its
+    own it is an ordinary differentiable module (_GlnOnly)."""
 
     def forward(self, y):
-        if torch.is_grad_enabled() and (y.requires_grad or self.gamma.requires_grad):
-            raise NotImplementedError("stand-alone GlobalLayerNorm has no backward: use it inside a TemporalBlock "
-                                      "(fused) or under torch.no_grad()")
         K = y.size(-1)
         yp = _pad_frames(y.to(torch.float32), K)
-        ch = yp.shape[1]
-        one_tap = torch.ones((ch, 1, 1), dtype=torch.float32, device=yp.device)
-        one = torch.ones((1,), dtype=torch.float32, device=yp.device)          # PReLU slope 1 = identity
-        _, stats = ops.dw_fwd(yp, one_tap, K, 1, False, epi_alpha=one)
-        out, _ = ops.dw_fwd(yp, one_tap, K, 1, False, pro=(stats, self.gamma, self.beta, one))
-        return out[..., :K]
+        return _GlnOnly.apply(yp, self.gamma, self.beta, K)[..., :K]

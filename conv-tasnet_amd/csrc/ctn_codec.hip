@@ -27,7 +27,8 @@ __global__ __launch_bounds__(NT) void im2col_kernel(const float* __restrict__ x,
     }
 }
 
-// sw[m,c,n,k] = w[m,n,k] * act(score[m,c,n,k]);  act = relu (mode 0) or softmax over c (mode 1)
+// sw[m,c,n,k] = w[m,n,k] * act(score[m,c,n,k]);  act = relu (mode 0), softmax over c (mode 1) or identity (mode 2: the
+// stand-alone Decoder.forward, whose est_mask argument already is a mask, src/conv_tasnet.py:140)
 __global__ __launch_bounds__(NT) void mask_apply_kernel(const float* __restrict__ score, const float* __restrict__ w,
                                                         float* __restrict__ sw, int M, int C, long long NK, int mode) {
     const long long n4 = (long long)M * NK / 4;
@@ -43,6 +44,11 @@ __global__ __launch_bounds__(NT) void mask_apply_kernel(const float* __restrict_
                 const float4 s = ld4(score + base + (size_t)c * NK);
                 *reinterpret_cast<float4*>(sw + base + (size_t)c * NK) =
                     make_float4(ww[0] * fmaxf(s.x, 0.f), ww[1] * fmaxf(s.y, 0.f), ww[2] * fmaxf(s.z, 0.f), ww[3] * fmaxf(s.w, 0.f));
+            }
+        } else if (mode == 2) {
+            for (int c = 0; c < C; ++c) {
+                const float4 s = ld4(score + base + (size_t)c * NK);
+                *reinterpret_cast<float4*>(sw + base + (size_t)c * NK) = make_float4(ww[0] * s.x, ww[1] * s.y, ww[2] * s.z, ww[3] * s.w);
             }
         } else {
             float sc[MAXC][4];
@@ -96,6 +102,13 @@ __global__ __launch_bounds__(NT) void mask_apply_bwd_kernel(const float* __restr
                     o[q] = sv[q] > 0.f ? gv[q] * ww[q] : 0.f;
                 }
                 *reinterpret_cast<float4*>(dscore + base + (size_t)c * NK) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else if (mode == 2) {
+            for (int c = 0; c < C; ++c) {
+                const float4 s = ld4(score + base + (size_t)c * NK);
+                const float4 g = ld4(dsw + base + (size_t)c * NK);
+                acc[0] += g.x * s.x; acc[1] += g.y * s.y; acc[2] += g.z * s.z; acc[3] += g.w * s.w;
+                *reinterpret_cast<float4*>(dscore + base + (size_t)c * NK) = make_float4(g.x * ww[0], g.y * ww[1], g.z * ww[2], g.w * ww[3]);
             }
         } else {
             float pr[MAXC][4], gm[MAXC][4];
@@ -171,6 +184,39 @@ __global__ __launch_bounds__(NT) void unfold_kernel(const float* __restrict__ de
     }
 }
 
+// General overlap-and-add, src/utils.py:9-47: out[b][j*step + l] += sig[b][j][l] for any frame_step (the reference
+// splits frames into gcd(frame_length, frame_step) sub-frames and index_add_s them).  Gather form: every output sample
+// sums, in ascending frame order, the <= ceil(frame_length / step) frames that cover it.  sig is [Bn, F, L] row-major
+// (the reference's [..., frames, frame_length]), out [Bn, (F-1)*step + L].
+__global__ __launch_bounds__(NT) void ola_general_kernel(const float* __restrict__ sig, float* __restrict__ out,
+                                                         int Bn, int F, int L, int step, int T) {
+    const long long n = (long long)Bn * T;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int t = (int)(i % T);
+        const int b = (int)(i / T);
+        const float* __restrict__ s = sig + (size_t)b * F * L;
+        int j0 = (t - L + step) / step;                  // first frame with j*step + L > t
+        if (t - L + step < 0) j0 = 0;
+        int j1 = t / step;
+        if (j1 > F - 1) j1 = F - 1;
+        float v = 0.f;
+        for (int j = j0; j <= j1; ++j) v += s[(size_t)j * L + (t - j * step)];
+        out[i] = v;
+    }
+}
+
+// backward: dsig[b][j][l] = dout[b][j*step + l]
+__global__ __launch_bounds__(NT) void ola_general_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsig,
+                                                             int Bn, int F, int L, int step, int T) {
+    const long long n = (long long)Bn * F * L;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n; i += (long long)gridDim.x * NT) {
+        const int l = (int)(i % L);
+        const int j = (int)((i / L) % F);
+        const int b = (int)(i / ((long long)L * F));
+        dsig[i] = dout[(size_t)b * T + (size_t)j * step + l];
+    }
+}
+
 unsigned grid_for(long long n) {
     long long b = ctn_cdivll(n, NT);
     if (b > 256 * 16) b = 256 * 16;   // grid-stride beyond 16 workgroups per CU
@@ -196,11 +242,12 @@ int ctn_im2col(const float* mix, float* xcol, int M, int T, int L, int Lp, int K
 int ctn_mask_apply(const float* score, const float* w, float* sw, int M, int C, int N, int Kp, int softmax, void* stream) {
     CTN_REQUIRE(score && w && sw, "ctn_mask_apply: null pointer");
     CTN_REQUIRE(M > 0 && C > 0 && N > 0 && Kp > 0 && Kp % 4 == 0, "ctn_mask_apply: bad sizes");
-    CTN_REQUIRE(!softmax || C <= MAXC, "ctn_mask_apply: softmax mask supports at most %d speakers", MAXC);
+    CTN_REQUIRE(softmax >= 0 && softmax <= 2, "ctn_mask_apply: mode must be 0 (relu), 1 (softmax) or 2 (identity)");
+    CTN_REQUIRE(softmax != 1 || C <= MAXC, "ctn_mask_apply: softmax mask supports at most %d speakers", MAXC);
     CTN_REQUIRE(aligned16(score) && aligned16(w) && aligned16(sw), "ctn_mask_apply: alignment");
     const long long NK = (long long)N * Kp;
     hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for((long long)M * NK / 4)), dim3(NT), 0, (hipStream_t)stream,
-                       score, w, sw, M, C, NK, softmax ? 1 : 0);
+                       score, w, sw, M, C, NK, softmax);
     CTN_CHECK_LAUNCH("ctn_mask_apply");
     return CTN_OK;
 }
@@ -209,11 +256,12 @@ int ctn_mask_apply_bwd(const float* dsw, const float* score, const float* w, flo
                        int M, int C, int N, int Kp, int softmax, void* stream) {
     CTN_REQUIRE(dsw && score && w && dscore && dw, "ctn_mask_apply_bwd: null pointer");
     CTN_REQUIRE(M > 0 && C > 0 && N > 0 && Kp > 0 && Kp % 4 == 0, "ctn_mask_apply_bwd: bad sizes");
-    CTN_REQUIRE(!softmax || C <= MAXC, "ctn_mask_apply_bwd: softmax mask supports at most %d speakers", MAXC);
+    CTN_REQUIRE(softmax >= 0 && softmax <= 2, "ctn_mask_apply_bwd: mode must be 0 (relu), 1 (softmax) or 2 (identity)");
+    CTN_REQUIRE(softmax != 1 || C <= MAXC, "ctn_mask_apply_bwd: softmax mask supports at most %d speakers", MAXC);
     CTN_REQUIRE(aligned16(dsw) && aligned16(score) && aligned16(w) && aligned16(dscore) && aligned16(dw), "ctn_mask_apply_bwd: alignment");
     const long long NK = (long long)N * Kp;
     hipLaunchKernelGGL(mask_apply_bwd_kernel, dim3(grid_for((long long)M * NK / 4)), dim3(NT), 0, (hipStream_t)stream,
-                       dsw, score, w, dscore, dw, M, C, NK, softmax ? 1 : 0);
+                       dsw, score, w, dscore, dw, M, C, NK, softmax);
     CTN_CHECK_LAUNCH("ctn_mask_apply_bwd");
     return CTN_OK;
 }
@@ -233,6 +281,27 @@ int ctn_unfold(const float* dest, float* dframes, int Bn, int T, int L, int Lp, 
     hipLaunchKernelGGL(unfold_kernel, dim3(grid_for((long long)Bn * Lp * Kp)), dim3(NT), 0, (hipStream_t)stream,
                        dest, dframes, Bn, T, L, Lp, L / 2, K, Kp);
     CTN_CHECK_LAUNCH("ctn_unfold");
+    return CTN_OK;
+}
+
+// general overlap_and_add(signal [Bn, frames, frame_length], frame_step) -> out [Bn, (frames-1)*frame_step + frame_length]
+int ctn_overlap_add(const float* signal, float* out, int Bn, int frames, int frame_length, int frame_step, void* stream) {
+    CTN_REQUIRE(signal && out, "ctn_overlap_add: null pointer");
+    CTN_REQUIRE(Bn > 0 && frames > 0 && frame_length > 0 && frame_step > 0, "ctn_overlap_add: bad sizes");
+    const int T = (frames - 1) * frame_step + frame_length;
+    hipLaunchKernelGGL(ola_general_kernel, dim3(grid_for((long long)Bn * T)), dim3(NT), 0, (hipStream_t)stream, signal, out,
+                       Bn, frames, frame_length, frame_step, T);
+    CTN_CHECK_LAUNCH("ctn_overlap_add");
+    return CTN_OK;
+}
+
+int ctn_overlap_add_bwd(const float* dout, float* dsignal, int Bn, int frames, int frame_length, int frame_step, void* stream) {
+    CTN_REQUIRE(dout && dsignal, "ctn_overlap_add_bwd: null pointer");
+    CTN_REQUIRE(Bn > 0 && frames > 0 && frame_length > 0 && frame_step > 0, "ctn_overlap_add_bwd: bad sizes");
+    const int T = (frames - 1) * frame_step + frame_length;
+    hipLaunchKernelGGL(ola_general_bwd_kernel, dim3(grid_for((long long)Bn * frames * frame_length)), dim3(NT), 0,
+                       (hipStream_t)stream, dout, dsignal, Bn, frames, frame_length, frame_step, T);
+    CTN_CHECK_LAUNCH("ctn_overlap_add_bwd");
     return CTN_OK;
 }
 

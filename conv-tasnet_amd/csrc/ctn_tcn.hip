@@ -460,6 +460,45 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------
+// Stand-alone gLN(prelu(Y)) backward, first pass (the fused path gets these sums from the GEMM / depthwise epilogues):
+// per (utterance, channel) row  S1 = sum_k g*dN, S2 = sum_k g*dN*xh  -> sums_part [M, H, 2] fp64, and the parameter-
+// gradient partials  pc[0] = sum_k dN*xh (dgamma), pc[1] = sum_k dN (dbeta)  -> pc [2, M, H].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gln_bwd_sums_kernel(const float* __restrict__ dN, const float* __restrict__ Y,
+                                                          int M, int H, int K, int Kp, const float* __restrict__ gamma,
+                                                          const float* __restrict__ alpha_p, const float* __restrict__ ms,
+                                                          double* __restrict__ sums_part, float* __restrict__ pc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hb = (H + ROWS - 1) / ROWS;
+    const int m = blockIdx.x / hb;
+    const int c = (blockIdx.x % hb) * ROWS + wave;
+    if (c >= H) return;
+    const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha_p[0], g = gamma[c];
+    const size_t row = ((size_t)m * H + c) * Kp;
+    float sdn = 0.f, sdx = 0.f;
+    for (int k = lane * 4; k < Kp; k += 256) {
+        const float4 dn = ld4(dN + row + k);
+        const float4 y = ld4(Y + row + k);
+        const float dv[4] = {dn.x, dn.y, dn.z, dn.w};
+        const float yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k + e < K) {
+                const float xh = (prelu_f(yv[e], al) - mean) * rstd;
+                sdn += dv[e];
+                sdx = fmaf(dv[e], xh, sdx);
+            }
+    }
+    const double d1 = wave_sum((double)sdn), d2 = wave_sum((double)sdx);
+    if (lane == 0) {
+        sums_part[((size_t)m * H + c) * 2] = (double)g * d1;
+        sums_part[((size_t)m * H + c) * 2 + 1] = (double)g * d2;
+        pc[(size_t)m * H + c] = (float)d2;
+        pc[(size_t)(M + m) * H + c] = (float)d1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // channel-wise LayerNorm (optionally after PReLU), per (m, frame) over channels.
 // block = 64 frames x 4 channel-groups (one wave each).
 // ---------------------------------------------------------------------------
@@ -932,6 +971,17 @@ int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, 
     hipLaunchKernelGGL(gln_prelu_bwd_kernel, dim3((unsigned)(M * ctn_cdiv(H, ROWS))), dim3(NT), 0, (hipStream_t)stream,
                        dN, Y, dY, M, H, K, Kp, gamma, alpha, ms, sums_part, nparts, dalpha_part);
     CTN_CHECK_LAUNCH("ctn_gln_prelu_bwd");
+    return CTN_OK;
+}
+
+int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int Kp, const float* gamma, const float* alpha,
+                     const float* ms, double* sums_part, float* pc, void* stream) {
+    CTN_REQUIRE(dN && Y && gamma && alpha && ms && sums_part && pc, "ctn_gln_bwd_sums: null pointer");
+    CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_gln_bwd_sums: bad sizes");
+    CTN_REQUIRE(aligned16(dN) && aligned16(Y), "ctn_gln_bwd_sums: alignment");
+    hipLaunchKernelGGL(gln_bwd_sums_kernel, dim3((unsigned)(M * ctn_cdiv(H, ROWS))), dim3(NT), 0, (hipStream_t)stream,
+                       dN, Y, M, H, K, Kp, gamma, alpha, ms, sums_part, pc);
+    CTN_CHECK_LAUNCH("ctn_gln_bwd_sums");
     return CTN_OK;
 }
 

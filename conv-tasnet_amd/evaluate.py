@@ -1,8 +1,10 @@
 """SI-SNRi evaluation (src/evaluate.py:21-130): forward + PIT reorder on the GPU, the numpy SI-SNR metric on host.
 
-``evaluate(model_or_path, data_loader, ...)`` takes any iterable of (padded_mixture, mixture_lengths, padded_source)
-batches -- the output contract of the reference's AudioDataLoader (src/data.py:264-300); wav/json reading (librosa)
-and SDRi (mir_eval, "very very slow", :78) are outside the hot-path scope.
+``evaluate(model_path, data_dir, calc_sdr, use_cuda, sample_rate, batch_size)`` is the reference's entry point
+(src/evaluate.py:21): it loads the checkpoint, reads data_dir/{mix,s1,s2}.json through data.AudioDataset (full
+utterances, scipy wav reader) and prints per-utterance and average SI-SNRi.  ``evaluate_loader(model, data_loader)`` is
+the same loop over any iterable of (padded_mixture, mixture_lengths, padded_source) batches.  calc_sdr needs mir_eval's
+bss_eval_sources (third party, CPU, "very very slow" :78): outside the hot-path scope, an explicit error here.
 """
 import numpy as np
 import torch
@@ -29,7 +31,20 @@ def cal_SISNRi(src_ref, src_est, mix):
     return (gains[0] + gains[1]) / 2
 
 
-def evaluate(model, data_loader, use_cuda=True, verbose=True):
+def evaluate(model_path, data_dir, calc_sdr=0, use_cuda=1, sample_rate=8000, batch_size=1):
+    """The reference's signature (src/evaluate.py:21-73).  -> average SI-SNRi over data_dir's utterances."""
+    if calc_sdr:
+        raise NotImplementedError("calc_sdr needs mir_eval.separation.bss_eval_sources (third party, CPU only): outside "
+                                  "the hot-path scope -- SI-SNRi is computed, SDRi is not")
+    from .data import AudioDataLoader, AudioDataset
+    model = ConvTasNet.load_model(model_path)
+    print(model)
+    dataset = AudioDataset(data_dir, batch_size, sample_rate=sample_rate, segment=-1)
+    data_loader = AudioDataLoader(dataset, batch_size=1, num_workers=2)
+    return evaluate_loader(model, data_loader, use_cuda=bool(use_cuda))
+
+
+def evaluate_loader(model, data_loader, use_cuda=True, verbose=True):
     """-> average SI-SNRi over every utterance of the loader.  `model` is a ConvTasNet or a checkpoint path."""
     if isinstance(model, str):
         model = ConvTasNet.load_model(model)

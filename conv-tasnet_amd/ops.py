@@ -97,6 +97,18 @@ def _sink(p):
     return getattr(p, "_ctn_grad_sink", None)
 
 
+def _claim_sinks(p):
+    """A backward stage is about to OVERWRITE the gradient sinks of its parameters (direct_grads: no accumulation).  A second
+    backward pass into the same sinks before zero_grad() would silently drop the first contribution, where the reference's
+    autograd accumulates: refuse it."""
+    owner = getattr(p, "_ctn_sink_owner", None)
+    if owner is not None:
+        if id(p) in owner._written:
+            raise CtnError("a second backward pass wrote into FlatAdam's gradient buffer without zero_grad() in between: "
+                           "direct gradients overwrite -- use FlatAdam(..., direct_grads=False) to accumulate over passes")
+        owner._written.add(id(p))
+
+
 def _emit(grad, sink):
     """Return `grad` to autograd, or copy it into the sink and return None."""
     if sink is None:
@@ -125,28 +137,10 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
                  _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
                  int(relu_out), _stream())
         return out, epi_part
-    probe = _stats_gemm_probe if (epi_alpha is not None and pro is None and not trans_w) else None
-    if probe is not None:           # measurement hook (bench.py): HIP events around this launch on its own stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, int(trans_w),
              _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
              int(relu_out), _stream())
-    if probe is not None:
-        e1.record()
-        probe.append((e0, e1, M, R, Cn, K))
     return out, epi_part
-
-
-_stats_gemm_probe = None
-
-
-def set_stats_gemm_probe(lst):
-    """bench.py's roofline leg: while `lst` is a list, every launch of the dominant kernel (the first 1x1 conv of a
-    block: GEMM + PReLU/gLN-statistics epilogue) is bracketed by two timing events appended to it.  None switches
-    the hook off (the default; the product path never times itself)."""
-    global _stats_gemm_probe
-    _stats_gemm_probe = lst
 
 
 def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
@@ -351,11 +345,17 @@ class Frontend(torch.autograd.Function):
             dx0 = torch.zeros((M, B, Kp), dtype=F32, device=w.device)
         dx0 = _c(dx0)
         sU, sg0, sb0, sWb = ctx.sinks
+        if sU is not None:
+            _claim_sinks(U)
         dy0, _ = pw_gemm(Wb, dx0, N, B, K, trans_w=True)
         dWb = pw_wgrad(dx0, y0, B, N, K, out=sWb)
         add = None if dw_dec is None else _c(dw_dec)
         g, dg0, db0, _ = cln_bwd(dy0, w, mean0, rstd0, g0, None, K, add=add, relu_ref=w)
         dU = pw_wgrad(g, xcol, N, L, K, out=sU)
+        # the first stage of the forward pass is the last node of the backward pass: every weight-gradient kernel of the
+        # second stream has been issued by now -- order the current stream after them, so that p.grad / flat_grads may be
+        # read right after loss.backward() (not only by FlatAdam.step / the all-reduce, which join as well)
+        join_side_stream(w.device)
         return (None, None if sU is not None else dU.view(N, 1, L), _emit(dg0.view(1, N, 1), sg0),
                 _emit(db0.view(1, N, 1), sb0), None if sWb is not None else dWb.view(B, N, 1))
 
@@ -387,6 +387,8 @@ class GlnBlock(torch.autograd.Function):
         x, h1, d, ms1, ms2, w1, a1, g1, b1, D, a2, g2, b2, w2 = ctx.saved_tensors
         sinks = ctx.sinks
         direct = all(t is not None for t in sinks)
+        if direct:
+            _claim_sinks(w1)
         K, dilation, causal = ctx.cfg
         dout = _c(dout)
         M, B, Kp = x.shape
@@ -526,6 +528,7 @@ class TcnGln(torch.autograd.Function):
         _chk(dout)
         direct = all(s is not None for s in ctx.sinks)
         if direct:
+            _claim_sinks(params[0])
             gdst, flat = ctx.sinks, None
         else:                       # plain autograd parameters: gradients land in one scratch buffer, returned as views
             sizes = [(p.numel() + 3) // 4 * 4 for p in params]
@@ -581,6 +584,8 @@ class ClnBlock(torch.autograd.Function):
         dev = x.device
         sk = ctx.sinks
         direct = all(t is not None for t in sk)       # FlatAdam: gradients go straight into the flat buffer
+        if direct:
+            _claim_sinks(w1)
         # The second stream does not pay here (22.7 vs 22.3 ms/step at paper size): the 1024-thread cLN kernels fill
         # every wave slot of a CU, so the weight gradients only time-slice with them.  CTN_CLN_SIDE=1 turns it on.
         side = direct and _SIDE_ENABLED and _CLN_SIDE
@@ -738,6 +743,8 @@ class Backend(torch.autograd.Function):
         lib.call("ctn_unfold", _p(dest), _p(dfr), M * C, T, L, L, K, Kp, _stream())
         dsw, _ = pw_gemm(V, dfr, N, L, K, trans_w=True)                 # [M*C, N, Kp]
         sWm, sV = ctx.sinks
+        if sWm is not None:
+            _claim_sinks(Wm)
         dV = pw_wgrad(dfr, sw.view(M * C, N, Kp), L, N, K, out=sV)
         dw = torch.empty((M, N, Kp), dtype=F32, device=dev)
         lib.call("ctn_mask_apply_bwd", _p(dsw), _p(score), _p(w), _p(dsw), _p(dw), M, C, N, Kp, int(softmax), _stream())

@@ -26,6 +26,7 @@ class FlatAdam(torch.optim.Optimizer):
         # AccumulateGrad add per tensor).  Semantics: a backward pass OVERWRITES the gradient, so accumulate over
         # several backward calls only with direct_grads=False.
         self.direct_grads = bool(direct_grads)
+        self._written = set()       # parameters whose sink a backward stage has overwritten since the last zero_grad()
         self._flatten()
         self._step = 0
         self.last_total_norm = None
@@ -57,6 +58,7 @@ class FlatAdam(torch.optim.Optimizer):
             p.grad = self.flat_grads[o:o + n].view(p.shape)
             if self.direct_grads:
                 p._ctn_grad_sink = p.grad
+                p._ctn_sink_owner = self
 
     def _grad_views_intact(self):
         base = self.flat_grads.data_ptr()
@@ -68,6 +70,7 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """One memset; the .grad views stay attached (set_to_none is ignored on purpose)."""
         self.flat_grads.zero_()
+        self._written.clear()
         if not self._grad_views_intact():
             for p, o in zip(self.param_groups[0]["params"], self._offsets):
                 p.grad = self.flat_grads[o:o + p.numel()].view(p.shape)
@@ -93,6 +96,7 @@ class FlatAdam(torch.optim.Optimizer):
         from . import ops
         ops.join_side_stream(self.flat_grads.device)      # weight-gradient kernels run on a second stream
         g = self.param_groups[0]
+        self._written.clear()
         self._step += 1
         b1, b2 = g["betas"]
         lib.call("ctn_clip_adam_step", self.flat_params.data_ptr(), self.flat_grads.data_ptr(), self.exp_avg.data_ptr(),

@@ -6,35 +6,36 @@ from ._lib import lib
 
 
 class _Ola(torch.autograd.Function):
-    """frames [Bn, K, L] -> [Bn, (K-1)*step + L]; gather formulation, deterministic."""
+    """frames [Bn, F, L] -> [Bn, (F-1)*step + L] for ANY frame_step (src/utils.py:9-47): ctn_overlap_add, a gather in
+    ascending frame order (deterministic, unlike the reference's index_add_ on a GPU)."""
 
     @staticmethod
     def forward(ctx, frames, step):
-        Bn, K, L = frames.shape
-        if step != L // 2:
-            raise NotImplementedError("HIP overlap_and_add implements the model's frame_step = frame_length // 2")
-        Kp = ops.padded_frames(K)
-        fr = frames.new_zeros((Bn, L, Kp))
-        fr[:, :, :K] = frames.transpose(1, 2)
-        T = (K - 1) * step + L
+        Bn, F, L = frames.shape
+        frames = frames.contiguous()
+        T = (F - 1) * step + L
         out = torch.empty((Bn, T), dtype=torch.float32, device=frames.device)
-        ops._chk(fr)
-        lib.call("ctn_ola", fr.data_ptr(), out.data_ptr(), Bn, T, L, L, K, Kp, ops._stream())
-        ctx.cfg = (K, L, Kp, T)
+        ops._chk(frames)
+        lib.call("ctn_overlap_add", frames.data_ptr(), out.data_ptr(), Bn, F, L, step, ops._stream())
+        ctx.cfg = (F, L, step)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        K, L, Kp, T = ctx.cfg
+        F, L, step = ctx.cfg
         dout = dout.contiguous()
         Bn = dout.shape[0]
-        dfr = torch.empty((Bn, L, Kp), dtype=torch.float32, device=dout.device)
-        lib.call("ctn_unfold", dout.data_ptr(), dfr.data_ptr(), Bn, T, L, L, K, Kp, ops._stream())
-        return dfr[:, :, :K].transpose(1, 2), None
+        dsig = torch.empty((Bn, F, L), dtype=torch.float32, device=dout.device)
+        ops._chk(dout)
+        lib.call("ctn_overlap_add_bwd", dout.data_ptr(), dsig.data_ptr(), Bn, F, L, step, ops._stream())
+        return dsig, None
 
 
 def overlap_and_add(signal, frame_step):
     """signal [..., frames, frame_length] -> [..., (frames-1)*frame_step + frame_length]  (src/utils.py:9-47)."""
+    frame_step = int(frame_step)
+    if frame_step < 1:
+        raise ValueError("frame_step must be positive")
     outer = signal.size()[:-2]
     frames, frame_length = signal.size()[-2:]
     flat = signal.reshape(-1, frames, frame_length).to(torch.float32)

@@ -129,6 +129,13 @@ int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, 
                       const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
                       float* dalpha_part, void* stream);
 
+/* First pass of the STAND-ALONE gLN(prelu(Y)) backward (GlobalLayerNorm used as a module of its own,
+ * src/conv_tasnet.py:338-361; inside a TemporalBlock these sums come out of the GEMM / depthwise epilogues):
+ * sums_part [M, H, 2] fp64 per-row (S1 = sum gamma*dN, S2 = sum gamma*dN*xhat) for ctn_gln_prelu_bwd, and
+ * pc [2, M, H]: row 0 the dgamma partials (sum dN*xhat), row 1 the dbeta partials (sum dN) -> ctn_reduce_mid. */
+int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int Kp, const float* gamma, const float* alpha,
+                     const float* ms, double* sums_part, float* pc, void* stream);
+
 /* ---- composite: the whole stack of gLN TemporalBlocks in one call ---------------------------------
  * replaces `temporal_conv_net = nn.Sequential(*repeats)`, src/conv_tasnet.py:176-186, i.e. nblocks = X*R
  * TemporalBlock.forward calls (:233-243) and their autograd backward.  The host side of a block (3 launches forward,
@@ -202,12 +209,18 @@ int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void*
  * decoder  src/conv_tasnet.py:140-145 : ctn_mask_apply + ctn_pw_gemm + ctn_ola (src/utils.py:9-47)
  * mask non-linearity src/conv_tasnet.py:208-214 (relu | softmax over speakers). */
 int ctn_im2col(const float* mix, float* xcol, int M, int T, int L, int Lp, int K, int Kp, void* stream);
+/* softmax: 0 = relu, 1 = softmax over speakers, 2 = identity (sw = w * score: the stand-alone Decoder.forward, :140) */
 int ctn_mask_apply(const float* score, const float* w, float* sw, int M, int C, int N, int Kp, int softmax, void* stream);
 int ctn_mask_apply_bwd(const float* dsw, const float* score, const float* w, float* dscore, float* dw,
                        int M, int C, int N, int Kp, int softmax, void* stream);
 /* est[b, t] = sum_{k*S+l = t} frames[b, l, k]; zeros for t >= (K-1)S+L (the F.pad of :59). frames:[Bn,Lp,Kp] */
 int ctn_ola(const float* frames, float* est, int Bn, int T, int L, int Lp, int K, int Kp, void* stream);
 int ctn_unfold(const float* dest, float* dframes, int Bn, int T, int L, int Lp, int K, int Kp, void* stream);
+/* overlap_and_add(signal, frame_step) for ANY frame_step, src/utils.py:9-47 (the reference splits frames into
+ * gcd(frame_length, frame_step) sub-frames and index_add_s them; here a deterministic gather in ascending frame order):
+ * signal [Bn, frames, frame_length] row-major -> out [Bn, (frames-1)*frame_step + frame_length]; _bwd is its adjoint. */
+int ctn_overlap_add(const float* signal, float* out, int Bn, int frames, int frame_length, int frame_step, void* stream);
+int ctn_overlap_add_bwd(const float* dout, float* dsignal, int Bn, int frames, int frame_length, int frame_step, void* stream);
 
 /* ---- PIT SI-SNR loss, src/pit_criterion.py:12-77 -----------------------------------------
  * source, estimate: [B,C,T]; lengths: [B] int64; perms: [nperm,C] int32 in itertools order.

@@ -124,7 +124,7 @@ def test_separate_writes_reference_named_files(tmp_path):
 
 
 def test_evaluate_sisnri_matches_oracle(capsys):
-    from conv_tasnet_amd.evaluate import evaluate, cal_SISNR
+    from conv_tasnet_amd.evaluate import evaluate_loader as evaluate, cal_SISNR
     torch.manual_seed(1)
     m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV)
     mix, lens, src = O.synth_batch(7, 2, 3000)
@@ -254,3 +254,60 @@ def test_composite_stack_is_bitwise_the_per_kernel_path(flat, causal, monkeypatc
     assert torch.equal(e1, e2) and torch.equal(l1, l2)
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+def test_evaluate_with_the_reference_signature(tmp_path, capsys):
+    """evaluate(model_path, data_dir, calc_sdr, use_cuda, sample_rate, batch_size), src/evaluate.py:21: checkpoint file +
+    {mix,s1,s2}.json manifests of wav files in, average SI-SNRi out; calc_sdr (mir_eval) is an explicit error."""
+    import json
+    from scipy.io import wavfile
+    from conv_tasnet_amd.evaluate import evaluate, evaluate_loader
+    torch.manual_seed(3)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV)
+    path = str(tmp_path / "m.pth.tar")
+    torch.save(m.serialize(m, torch.optim.Adam(m.parameters()), 1), path)
+    mix, lens, src = O.synth_batch(11, 3, 2400)
+    src = src / src.abs().max() * 0.4
+    manifests = {"mix": [], "s1": [], "s2": []}
+    for u in range(3):
+        n = 2400 - 300 * u
+        sig = {"s1": src[u, 0, :n], "s2": src[u, 1, :n]}
+        sig["mix"] = sig["s1"] + sig["s2"]
+        for k, v in sig.items():
+            p = str(tmp_path / ("%s_%d.wav" % (k, u)))
+            wavfile.write(p, 8000, (v.numpy() * 32767).astype(np.int16))
+            manifests[k].append([p, n])
+    for k, v in manifests.items():
+        (tmp_path / (k + ".json")).write_text(json.dumps(v))
+    got = evaluate(path, str(tmp_path), 0, 1, 8000, 2)
+    from conv_tasnet_amd.data import AudioDataLoader, AudioDataset
+    want = evaluate_loader(m, AudioDataLoader(AudioDataset(str(tmp_path), 2, sample_rate=8000, segment=-1)), verbose=False)
+    assert abs(got - want) < 1e-6 and "Average SISNR improvement" in capsys.readouterr().out
+    with pytest.raises(NotImplementedError):
+        evaluate(path, str(tmp_path), 1, 1, 8000, 2)
+
+
+def test_direct_gradients_refuse_silent_overwrite_and_are_readable_after_backward():
+    """FlatAdam(direct_grads=True): the backward stages overwrite the flat gradient buffer.  A second backward pass without
+    zero_grad() must raise (the reference's autograd would accumulate), and right after loss.backward() the gradients are
+    complete in stream order (the weight-gradient stream is joined by the last backward node), so reading them is safe."""
+    from conv_tasnet_amd import CtnError
+    torch.manual_seed(5)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 2, 2).to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    mix, lens, src = O.synth_batch(21, 2, 3000)
+
+    def backprop():
+        ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0].backward()
+
+    opt.zero_grad()
+    backprop()
+    g1 = opt.flat_grads.clone()                 # same stream, no explicit join: must already be final
+    torch.cuda.synchronize()
+    assert torch.equal(g1, opt.flat_grads) and float(g1.abs().max()) > 0
+    with pytest.raises(CtnError):
+        backprop()
+    opt.zero_grad()
+    backprop()                                  # fine again after zero_grad()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, opt.flat_grads)
