@@ -156,7 +156,12 @@ def _family(name, a):
     if name == "ctn_pw_dgrad_gln":
         return "B1 pw_gemm<T,EPI_GLN_BWD> (input gradient W2^T.dout + gLN backward sums)", "mfma", (a[3], a[4], a[5])
     if name == "ctn_pw_wgrad":
-        fam = "B2 pw_wgrad<PRO> + slab_reduce (dW2)" if a[11] else "B6 pw_wgrad + slab_reduce (dW1 and the small layers)"
+        if a[11]:
+            fam = "B2 pw_wgrad<PRO> + slab_reduce (dW2 = dout . gLN2(prelu(d))^T)"
+        elif a[4] * a[5] >= 256 * 256:
+            fam = "B6 pw_wgrad + slab_reduce (dW1 = dh1 . x^T)"
+        else:
+            fam = "pw_wgrad + slab_reduce, small layers (encoder / decoder bases)"
         return fam, "mfma", (a[3], a[4], a[5])
     return {"ctn_dw_fwd": "K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)",
             "ctn_dw_bwd": "B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)",
@@ -197,14 +202,15 @@ def family_table(probe, cfg, K, steps):
 def roofline(rows, probe_steps):
     dom = rows[0]
     traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_dominant_kernel.json")
-    if os.path.exists(pmc):
-        try:
-            j = json.load(open(pmc))
-            if j.get("family", "")[:2] == dom["family"][:2]:
-                traffic, src = j.get("hbm_bytes_per_launch"), "profiles/r02_pmc_dominant_kernel.json"
-        except Exception:
-            pass
+    for pmc in ("r02_pmc_wgrad_dW1.json", "r02_pmc_wgrad_dW2_pro.json"):      # PMC passes of the two weight-gradient kernels
+        path = os.path.join(ROOT, "profiles", pmc)
+        if os.path.exists(path):
+            try:
+                j = json.load(open(path))
+                if j.get("family", "")[:2] == dom["family"][:2]:
+                    traffic, src = j.get("hbm_bytes_per_launch"), "profiles/" + pmc
+            except Exception:
+                pass
     return {"bound": dom["bound"], "kernel": dom["family"], "achieved": dom.get("achieved"),
             "peak": PEAK_F32_MFMA_TFLOPS if dom["bound"] == "mfma" else PEAK_HBM_GBS, "unit": dom.get("unit"),
             "frac": dom.get("frac"), "us_per_launch": dom["us_per_launch"], "launches_per_step": dom["launches_per_step"],

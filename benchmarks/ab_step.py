@@ -18,9 +18,17 @@ configs = sys.argv[1:] or ["pk=1", "pk=0"]
 rounds, steps = int(os.environ.get("ROUNDS", "5")), int(os.environ.get("STEPS", "8"))
 dev = "cuda:0"
 torch.manual_seed(0)
-m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(dev)
+CONFIG = os.environ.get("CONFIG", "paper")          # paper | causal | c3  (bench.py's workloads)
+if CONFIG == "causal":
+    m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2, norm_type="cLN", causal=True).to(dev)
+    mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=32000)))
+elif CONFIG == "c3":
+    m = ctn.ConvTasNet(256, 16, 256, 512, 3, 8, 4, 3).to(dev)
+    mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=64000, C=3, sample_rate=16000)))
+else:
+    m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(dev)
+    mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=32000)))
 opt = FlatAdam(m.parameters(), lr=1e-3)
-mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=32000)))
 mix, lens, src = mix.to(dev), lens.to(dev), src.to(dev)
 
 
@@ -33,6 +41,8 @@ def apply(cfg):
             ops._COMPOSITE = bool(int(v))
         elif k == "side":
             ops._SIDE_ENABLED = bool(int(v))
+        elif k == "cln_side":
+            ops._CLN_SIDE = bool(int(v))
         else:
             ctn.lib.call("ctn_tune", k.encode(), int(v))
     ops._ws_cache.clear()

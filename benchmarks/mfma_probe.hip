@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -336,6 +337,35 @@ int main(int argc, char** argv) {
         run_coexec<PART_GLOAD, false>("global_load x4", it, it * 16 * 64 / 64 / 8);
         run_coexec<PART_MFMA, false>("fp32 MFMA", it, it);
         fflush(stdout);
+    }
+    if (which == 5) {
+        // power mode (benchmarks/power_lab.sh mfma): each configuration runs back to back for ~3 s while the shell samples
+        // rocm-smi; prints "case <name> <t0> <t1> <launches> <us per launch>" with wall-clock timestamps
+        auto now = [] { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+        auto run = [&](const char* name, auto launch, double flop_per_launch) {
+            launch(); CK(hipDeviceSynchronize());
+            const double t0 = now();
+            long n = 0;
+            while (now() - t0 < 3.0) { for (int i = 0; i < 20; ++i) launch(); CK(hipDeviceSynchronize()); n += 20; }
+            const double t1 = now();
+            printf("case %s %.3f %.3f %ld %.2f  # %.1f TFLOP/s\n", name, t0, t1, n, (t1 - t0) / n * 1e6, flop_per_launch * n / (t1 - t0) / 1e12);
+            fflush(stdout);
+            struct timespec sl = {0, 400000000}; nanosleep(&sl, nullptr);
+        };
+        const int it = 4000;
+        const double f32 = 256.0 * 4 * 4 * it * 16 * 4096.0;        // 4 blocks per CU
+        run("mfma32x32x2_4w_regs", [&] { hipLaunchKernelGGL(peak32<4>, dim3(1024), dim3(256), 0, 0, d_in, d_out, it, d_clk); }, f32);
+        run("mfma32x32x2_1w_regs", [&] { hipLaunchKernelGGL(peak32<4>, dim3(256), dim3(256), 0, 0, d_in, d_out, it * 4, d_clk); }, f32);
+        run("mfma16x16x4_4w_regs", [&] { hipLaunchKernelGGL(peak16<4>, dim3(1024), dim3(256), 0, 0, d_in, d_out, it, d_clk); }, 256.0 * 4 * 4 * it * 32 * 2048.0);
+        const double fco = 256.0 * 4 * it * 16 * 4096.0;
+        run("mfma+ds_read_b32", [&] { hipLaunchKernelGGL((coexec<PART_DSREAD, true, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, it * 16 * 64 / 8 / 32, d_clk); }, fco);
+        run("mfma+ds_write_b128", [&] { hipLaunchKernelGGL((coexec<PART_DSWRITE128, true, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, it * 16 * 64 / 16 / 7, d_clk); }, fco);
+        run("mfma+global_load", [&] { hipLaunchKernelGGL((coexec<PART_GLOAD, true, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, it * 16 * 64 / 64 / 8, d_clk); }, fco);
+        run("mfma_alone_2w_wg", [&] { hipLaunchKernelGGL((coexec<PART_NONE, true, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, 0, d_clk); }, fco);
+        run("ds_read_b32_alone", [&] { hipLaunchKernelGGL((coexec<PART_DSREAD, false, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, it * 16 * 64 / 8 / 32, d_clk); }, 0);
+        run("global_load_alone", [&] { hipLaunchKernelGGL((coexec<PART_GLOAD, false, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, it * 16 * 64 / 64 / 8, d_clk); }, 0);
+        run("v_fma_alone", [&] { hipLaunchKernelGGL((coexec<PART_FMA32, false, false>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it, it * 16 * 64 / 4 / 32, d_clk); }, 0);
+        run("bf16_mfma_2w_wg", [&] { hipLaunchKernelGGL((coexec<PART_NONE, true, true>), dim3(256), dim3(512), 0, 0, d_in, d_out, d_big, it * 2, 0, d_clk); }, 256.0 * 4 * it * 2 * 16 * 32768.0);
     }
     if (which == 0 || which == 4) {
         printf("P4 control: the same with v_mfma_f32_32x32x16_bf16 in waves 0-3\n");

@@ -1,19 +1,33 @@
-# HBM traffic of the dominant GEMM (K1 shape): FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section).
-# usage (GPU box): bash benchmarks/pmc_traffic.sh   -> gpurun_out/pmc_traffic.txt
+# HBM traffic of one kernel from the PMC counters, as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in
+# SEPARATE passes (TCC slots), FETCH_SIZE doubled on gfx950 for wide coalesced reads, WRITE_SIZE exact.
+# usage (GPU box): bash benchmarks/pmc_traffic.sh <kernel-name-substring> <script.py> <out.json> [family label]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+PAT=$1; SCRIPT=$2; OUT=$3; FAM=${4:-}; SARGS=${5:-}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_traffic_$c -o p --output-format csv -- python3 $R/benchmarks/dominant_kernel.py -1 > $R/gpurun_out/pmc_traffic_$c.log 2>&1 || echo "$c pass failed"
+  rm -rf $R/gpurun_out/pmc_traffic_$c
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_traffic_$c -o p --output-format csv -- python3 $R/$SCRIPT $SARGS > $R/gpurun_out/pmc_traffic_$c.log 2>&1 || echo "$c pass failed"
 done
 cd $R
-python3 - <<PY
-import csv, glob, collections
-agg = collections.defaultdict(list)
-for f in glob.glob('gpurun_out/pmc_traffic_*/*counter_collection.csv'):
+PAT="$PAT" OUT="$OUT" FAM="$FAM" SCRIPT="$SCRIPT" python3 - <<'PY'
+import csv, glob, collections, json, os
+pat = os.environ["PAT"]
+agg, name = collections.defaultdict(list), None
+for f in glob.glob('gpurun_out/pmc_traffic_*/*counter_collection.csv') + glob.glob('gpurun_out/pmc_traffic_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'pw_gemm' in r['Kernel_Name']:
+        if pat in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
+            name = r['Kernel_Name']
+res = {"kernel": name, "family": os.environ["FAM"],
+       "command": "bash benchmarks/pmc_traffic.sh '%s' %s  (rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE)" % (pat, os.environ["SCRIPT"])}
 for c, v in sorted(agg.items()):
-    print('%s mean over launches 4.. : %.2f KB (n=%d)' % (c, sum(v[3:]) / max(1, len(v[3:])), len(v)))
+    v = v[3:] if len(v) > 6 else v
+    res[c + "_KB_mean"] = round(sum(v) / max(1, len(v)), 2)
+    res[c + "_launches"] = len(v)
+if "FETCH_SIZE_KB_mean" in res and "WRITE_SIZE_KB_mean" in res:
+    res["correction"] = "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact"
+    res["hbm_bytes_per_launch"] = int(round((2 * res["FETCH_SIZE_KB_mean"] + res["WRITE_SIZE_KB_mean"]) * 1024))
+json.dump(res, open(os.environ["OUT"], "w"), indent=1)
+print(json.dumps(res, indent=1))
 PY

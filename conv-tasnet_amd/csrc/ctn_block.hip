@@ -15,6 +15,7 @@
 #include <vector>
 
 extern "C" int ctn_pw_uses_pk(void);       // ctn_gemm.hip
+int g_ctn_block_wt = 1;                     // ctn_tune("block_wt", 0): forward GEMMs on the stored [O, I] weights (A/B runs)
 
 namespace {
 
@@ -81,7 +82,7 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     // [I, O] copies of both 1x1 weights of every block (the fast operand form of the persistent GEMM), one launch each
     float* const wt = (float*)((char*)workspace + w.wt);
     const size_t wsz = align256((size_t)H * B * sizeof(float)) / sizeof(float);
-    const bool use_wt = ctn_pw_uses_pk() != 0;      // the round-1 kernels (CTN_PW_KERNEL=1, A/B runs) take the stored weights
+    const bool use_wt = g_ctn_block_wt != 0;        // [I, O] weight copies: 16-byte LDS row writes instead of the transposing scatter
     if (use_wt) {
         std::vector<const void*> src(nblocks);
         std::vector<void*> dst(nblocks);

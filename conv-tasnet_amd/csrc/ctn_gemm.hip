@@ -134,21 +134,46 @@ __global__ __launch_bounds__(TL::NTH) void pw_gemm_kernel(PwArgs a) {
 
     const int l31 = lane & 31, lhi = lane >> 5;
     auto compute = [&](int buf) {
-        const float* const Ab = As + buf * BK * LDA + wm * WM + l31;
-        const float* const Bb = Bs + buf * BK * LDB + wn * WN + l31;
+        if constexpr (TL::MF == 16) {
+            // v_mfma_f32_16x16x4_f32: lane l supplies A[row l % 16][k l / 16] and B[k l / 16][column l % 16]; a 32x32 sub-tile
+            // is 2x2 instruction tiles (accumulator elements 4q .. 4q+3 of sub-tile q = 2 si + sj), contraction step 4
+            const float* const Ab = As + buf * BK * LDA + (lane >> 4) * LDA + wm * WM + (lane & 15);
+            const float* const Bb = Bs + buf * BK * LDB + (lane >> 4) * LDB + wn * WN + (lane & 15);
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const int kk = 2 * s + lhi;
-            float av[MT], bv[NTL];
+            for (int s = 0; s < BK / 4; ++s) {
+                float av[MT][2], bv[NTL][2];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) av[i] = Ab[kk * LDA + 32 * i];
+                for (int i = 0; i < MT; ++i) { av[i][0] = Ab[4 * s * LDA + 32 * i]; av[i][1] = Ab[4 * s * LDA + 32 * i + 16]; }
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) bv[j] = Bb[kk * LDB + 32 * j];
+                for (int j = 0; j < NTL; ++j) { bv[j][0] = Bb[4 * s * LDB + 32 * j]; bv[j][1] = Bb[4 * s * LDB + 32 * j + 16]; }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4v c = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][q >> 1], bv[j][q & 1], c, 0, 0, 0);
+                            acc[i][j][4 * q] = c[0]; acc[i][j][4 * q + 1] = c[1]; acc[i][j][4 * q + 2] = c[2]; acc[i][j][4 * q + 3] = c[3];
+                        }
+            }
+        } else {
+            const float* const Ab = As + buf * BK * LDA + wm * WM + l31;
+            const float* const Bb = Bs + buf * BK * LDB + wn * WN + l31;
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                const int kk = 2 * s + lhi;
+                float av[MT], bv[NTL];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = Ab[kk * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) bv[j] = Bb[kk * LDB + 32 * j];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -690,7 +715,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_kernel(WgArgs a) {
 // groups of a b128 read.  Per 16-frame k-tile and wave: 8 MFMAs, 4 ds_read_b128, 2 ds_write_b128, 2 buffer loads.
 constexpr int W4LD = 20;
 
-template <int PRO>
+template <int PRO, int MF>      // MF = 32: v_mfma_f32_32x32x2_f32;  16: v_mfma_f32_16x16x4_f32 (see Tile)
 __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][64][W4LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][64][W4LD];
@@ -736,17 +761,39 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const float* const fA = &As[0][wm * 32 + l31][4 * lhi];
-    const float* const fB = &Bs[0][wn * 32 + l31][4 * lhi];
+    // MF = 32: lane (row l % 32, k slot l / 32) reads frames 8j + 4 (l / 32) .. +3 of its row, twice per 16-frame k-tile;
+    // MF = 16: lane (row l % 16, k slot l / 16) reads frames 4 (l / 16) .. +3 of its row in each 16-row half of the sub-tile
+    const float* const fA = MF == 16 ? &As[0][wm * 32 + (lane & 15)][4 * (lane >> 4)] : &As[0][wm * 32 + l31][4 * lhi];
+    const float* const fB = MF == 16 ? &Bs[0][wn * 32 + (lane & 15)][4 * (lane >> 4)] : &Bs[0][wn * 32 + l31][4 * lhi];
     auto compute = [&](int buf) {
+        if constexpr (MF == 16) {
+            float4 av[2], bv[2];
 #pragma unroll
-        for (int j = 0; j < WK / 8; ++j) {
-            const float4 av = *reinterpret_cast<const float4*>(fA + buf * 64 * W4LD + 8 * j);
-            const float4 bv = *reinterpret_cast<const float4*>(fB + buf * 64 * W4LD + 8 * j);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                av[h] = *reinterpret_cast<const float4*>(fA + buf * 64 * W4LD + h * 16 * W4LD);
+                bv[h] = *reinterpret_cast<const float4*>(fB + buf * 64 * W4LD + h * 16 * W4LD);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)          // contraction step: frames 4 g + i of the k-tile, g = lane / 16
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {    // sub-tile q = 2 si + sj of the wave's 32x32 tile
+                    const float4 x = av[q >> 1], y = bv[q & 1];
+                    const float xa = i == 0 ? x.x : i == 1 ? x.y : i == 2 ? x.z : x.w;
+                    const float yb = i == 0 ? y.x : i == 1 ? y.y : i == 2 ? y.z : y.w;
+                    f32x4v c = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, yb, c, 0, 0, 0);
+                    acc[4 * q] = c[0]; acc[4 * q + 1] = c[1]; acc[4 * q + 2] = c[2]; acc[4 * q + 3] = c[3];
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WK / 8; ++j) {
+                const float4 av = *reinterpret_cast<const float4*>(fA + buf * 64 * W4LD + 8 * j);
+                const float4 bv = *reinterpret_cast<const float4*>(fB + buf * 64 * W4LD + 8 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
         }
     };
     // prefetch distance 2: k-tile kt+1 waits in one register set, kt+2 is in flight into the other
@@ -772,18 +819,29 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
     }
     // slab [split][R][Cn]: two 128-byte row segments per store instruction, rows / columns past the matrix dropped
     const __amdgpu_buffer_rsrc_t rsS = make_rsrc(a.slab + (size_t)sp * a.R * a.Cn, (unsigned)a.R * (unsigned)a.Cn * 4u);
-    const int c = c0 + wn * 32 + l31;
-    const int voS = c < a.Cn ? ((r0 + wm * 32 + 4 * lhi) * a.Cn + c) * 4 : 0x7fffffff;
+    if constexpr (MF == 16) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float v = acc[e];       // (clang lowers __builtin_bit_cast of a vector ELEMENT to element 0: go through a scalar)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsS, voS, ((e & 3) + 8 * (e >> 2)) * a.Cn * 4, 0);
+        for (int e = 0; e < 16; ++e) {          // element 4q + r: row 16 si + 4 (lane / 16) + r, column 16 sj + lane % 16
+            const int c = c0 + wn * 32 + 16 * ((e >> 2) & 1) + (lane & 15);
+            const int vo = c < a.Cn ? ((r0 + wm * 32 + 4 * (lane >> 4)) * a.Cn + c) * 4 : 0x7fffffff;
+            const float v = acc[e];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsS, vo, (16 * (e >> 3) + (e & 3)) * a.Cn * 4, 0);
+        }
+    } else {
+        const int c = c0 + wn * 32 + l31;
+        const int voS = c < a.Cn ? ((r0 + wm * 32 + 4 * lhi) * a.Cn + c) * 4 : 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = acc[e];       // (clang lowers __builtin_bit_cast of a vector ELEMENT to element 0: go through a scalar)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsS, voS, ((e & 3) + 8 * (e >> 2)) * a.Cn * 4, 0);
+        }
     }
 }
 
 }  // namespace
 
 int g_ctn_tile_override = -2;
+extern int g_ctn_block_wt;          // ctn_block.hip
 
 template <typename TL>
 static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd,
@@ -791,7 +849,10 @@ static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, b
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
-        if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+        if (pro && residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else if (pro) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+        else if (stats) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+        else if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
     } else if (pro) {
         if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
@@ -915,16 +976,11 @@ static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool sta
     tile_dims(id, &tm, &tn);
     a.tiles_r = ctn_cdiv(a.R, tm);
     a.tiles_c = ctn_cdiv(a.Kp, tn);
-    switch (id) {
-        case 1: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 8: launch_tile<T128x128w8>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 9: launch_tile<T128x64w8k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+    switch (id) {      // (ids 2 and 4..9, round-1 experiments that lost every A/B, share the instantiations of their nearest shape)
+        case 11: launch_tile<T64x64m16>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 3: case 5: launch_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 1: case 4: case 6: case 9: launch_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 2: launch_tile<T64x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 3: launch_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 4: launch_tile<T128x64w>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 5: launch_tile<T64x64k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 6: launch_tile<T128x64k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 7: launch_tile<T128x128k32>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         default: launch_tile<T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
     }
 }
@@ -933,7 +989,7 @@ extern "C" {
 
 // experiment / autotune hook: force a tile id (0..4) for every ctn_pw_gemm / ctn_pw_dgrad_gln, -1 = heuristic
 int ctn_tune_pw_tile(int id) {
-    if (id < -1 || id > 10) return CTN_ERR_ARG;
+    if (id < -1 || id > 11) return CTN_ERR_ARG;
     g_ctn_tile_override = id;
     return CTN_OK;
 }
@@ -959,7 +1015,6 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     CTN_REQUIRE(!(residual && epi_part), "ctn_pw_gemm: residual and stats epilogues are exclusive");
     CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0), "ctn_pw_gemm: incomplete prologue arguments");
     CTN_REQUIRE(!epi_part || epi_alpha, "ctn_pw_gemm: stats epilogue needs alpha");
-    CTN_REQUIRE(use_pk() || !(trans_w && (pro_part || epi_part)), "ctn_pw_gemm: fused prologue/stats only with trans_w=0");
     CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm: residual must be 16-byte aligned");
     PwArgs a{};
     a.store_f32 = 1;
@@ -1006,6 +1061,7 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
 
 extern "C" {
 
+static int g_w4_mf = 32;          // MFMA tile of the w4 kernel: 32 (32x32x2) or 16 (16x16x4); ctn_tune("wgrad_mf", ...)
 static int g_w4 = -1;             // weight-gradient kernel: 1 = "w4" (16-byte LDS traffic), 0 = the round-1 kernel
 static int g_wgrad_tile = 0;      // 0: heuristic; 64, 128: square tiles; 12864: 128 x 64 (ctn_tune_wgrad)
 static int g_wgrad_blocks = 512;   // target workgroups per launch
@@ -1042,6 +1098,9 @@ int ctn_tune(const char* key, int value) {
     if (!strcmp(key, "pk")) g_pk = value ? 1 : 0;
     else if (!strcmp(key, "pk_wgs") && value >= 0 && value <= 16) g_pk_wgs = value;
     else if (!strcmp(key, "wgrad_kernel")) g_w4 = value ? 1 : 0;
+    else if (!strcmp(key, "pw_tile") && value >= -1 && value <= 11) g_ctn_tile_override = value;
+    else if (!strcmp(key, "block_wt")) g_ctn_block_wt = value ? 1 : 0;
+    else if (!strcmp(key, "wgrad_mf") && (value == 16 || value == 32)) g_w4_mf = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
@@ -1085,8 +1144,13 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     if (g_w4 < 0) { const char* e = getenv("CTN_WGRAD_KERNEL"); g_w4 = (e && *e && atoi(e) == 1) ? 0 : 1; }   // 1 = the round-1 kernel (A/B runs)
     const int w4 = g_w4;
     if (wt == 64 && w4 && Kp % WK == 0) {
-        if (pro_ms) hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_PRELU_NORM>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_NONE>), grid, block, 0, st, a);
+        if (g_w4_mf == 16) {
+            if (pro_ms) hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_PRELU_NORM, 16>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_NONE, 16>), grid, block, 0, st, a);
+        } else {
+            if (pro_ms) hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_PRELU_NORM, 32>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((pw_wgrad4_kernel<PRO_NONE, 32>), grid, block, 0, st, a);
+        }
     } else if (wt == 64) {
         if (pro_ms) hipLaunchKernelGGL((pw_wgrad_kernel<PRO_PRELU_NORM, 64, 64>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_wgrad_kernel<PRO_NONE, 64, 64>), grid, block, 0, st, a);

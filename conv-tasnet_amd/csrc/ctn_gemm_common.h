@@ -19,12 +19,21 @@ enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI
 // Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
 // in 32x32 MFMA tiles.  Smaller tiles trade operand reuse (plentiful: one fp32 MFMA = 64 cycles for one
 // A and one B dword per lane) for finer load balance over the 256 CUs.
-template <int BM_, int BN_, int WGM_, int WGN_, int BK_ = 16>
+// MF_ = edge of the MFMA instruction tile: 32 -> v_mfma_f32_32x32x2_f32, 16 -> v_mfma_f32_16x16x4_f32 (each 32x32 sub-tile
+// of a wave is then 2x2 MFMA tiles).  Same FLOP rate (64 FLOP/clk/SIMD), same operand bytes per FLOP at this blocking,
+// but the 16x16x4 form moves half the accumulator bytes per FLOP: a bare loop at 155 TFLOP/s draws 990 W against 1087 W
+// (profiles/r02_b_power_lab_mfma.txt) -- and the training step runs AT the 1400 W package power cap, where energy per
+// step, not issue rate, sets the step time.
+template <int BM_, int BN_, int WGM_, int WGN_, int BK_ = 16, int MF_ = 32>
 struct Tile {
+    static constexpr int MF = MF_;
     static constexpr int TM = BM_, TN = BN_, WGM = WGM_, WGN = WGN_, TK = BK_;
     static constexpr int WM = BM_ / WGM_, WN = BN_ / WGN_;
     static constexpr int MT = WM / 32, NTL = WN / 32;
-    static constexpr int LDA = BM_ + 4, LDB = BN_ + 4, LDS_ST = WN + 4;
+    // LDS row pitches: 32x32x2 fragments read 32 consecutive floats of ONE k row per half-wave (pad 4: the transposing
+    // scatter of TRANS_W = 0); 16x16x4 fragments read 16 floats of TWO consecutive k rows per half-wave, which must sit
+    // 16 banks apart: pitch = 16 mod 32
+    static constexpr int LDA = MF_ == 16 ? BM_ + 16 : BM_ + 4, LDB = MF_ == 16 ? BN_ + 16 : BN_ + 4, LDS_ST = WN + 4;
     static constexpr int MAIN_FLOATS = 2 * BK_ * (LDA + LDB);
     static constexpr int NW = WGM_ * WGN_, NTH = 64 * NW;          // waves / threads per workgroup
     static constexpr int STAGE_FLOATS = NW * 32 * LDS_ST;
@@ -35,6 +44,7 @@ using T128x128 = Tile<128, 128, 2, 2>;
 using T128x64 = Tile<128, 64, 2, 2>;
 using T64x128 = Tile<64, 128, 2, 2>;
 using T64x64 = Tile<64, 64, 2, 2>;
+using T64x64m16 = Tile<64, 64, 2, 2, 16, 16>;     // the same tile on v_mfma_f32_16x16x4_f32
 using T128x64w = Tile<128, 64, 4, 1>;
 using T64x64k32 = Tile<64, 64, 2, 2, 32>;
 using T128x64k32 = Tile<128, 64, 2, 2, 32>;
@@ -177,7 +187,10 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                stage[((e & 3) + 8 * (e >> 2) + 4 * lhi) * LST + nt * 32 + l31] = acc[mt][nt][e];
+                if constexpr (TL::MF == 16)      // element 4q + r of sub-tile q = 2*si + sj: row 16 si + 4 (lane / 16) + r, column 16 sj + lane % 16
+                    stage[(16 * (e >> 3) + 4 * (lane >> 4) + (e & 3)) * LST + nt * 32 + 16 * ((e >> 2) & 1) + (lane & 15)] = acc[mt][nt][e];
+                else
+                    stage[((e & 3) + 8 * (e >> 2) + 4 * lhi) * LST + nt * 32 + l31] = acc[mt][nt][e];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < 32 / RPP; ++p) {
@@ -300,10 +313,11 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
 // id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32,
 //     8 / 9 = 128x128 / 128x64 with 8 waves (512 threads; the fp32 128x64 variant uses BK = 32)
 //     10 = 128x128 wave-specialised (split-bf16 forward/dgrad kernels only; fp32 kernels map it to 0)
+//     11 = 64x64 on v_mfma_f32_16x16x4_f32 (fp32 kernels)
 extern int g_ctn_tile_override;   // -2: not read yet, -1: heuristic (defined in ctn_gemm.hip)
 
 static void tile_dims(int id, int* tm, int* tn) {
-    static const int d[11][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}, {128, 128}};
+    static const int d[12][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}, {128, 128}, {64, 64}};
     *tm = d[id][0];
     *tn = d[id][1];
 }
@@ -312,7 +326,7 @@ static int pick_tile(int M, int R, int Kp) {
     if (g_ctn_tile_override == -2) {
         const char* e = getenv("CTN_PW_TILE");
         g_ctn_tile_override = (e && *e) ? atoi(e) : -1;
-        if (g_ctn_tile_override < -1 || g_ctn_tile_override > 10) g_ctn_tile_override = -1;
+        if (g_ctn_tile_override < -1 || g_ctn_tile_override > 11) g_ctn_tile_override = -1;
     }
     if (g_ctn_tile_override >= 0) return g_ctn_tile_override;
     // Measured on MI355X (benchmarks/gemm_sweep.py, paper shapes): 64x64 tiles win every variant -- 3200 / 1600

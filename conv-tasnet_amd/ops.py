@@ -166,7 +166,7 @@ _ws_cache = {}
 # FlatAdam.step()/the gradient all-reduce join the stream again (join_side_stream()).
 _side = {}
 _SIDE_ENABLED = os.environ.get("CTN_SIDE_STREAM", "1") != "0"
-_CLN_SIDE = os.environ.get("CTN_CLN_SIDE", "0") != "0"
+_CLN_SIDE = os.environ.get("CTN_CLN_SIDE", "1") != "0"     # round 2 (w4 weight-gradient kernel, 5 us slab reduce): 20.07 vs 21.7 ms/step
 _SIDE_FIN = os.environ.get("CTN_SIDE_FIN", "0") != "0"   # finishing reductions on the side stream too: measured slower (464 vs 490)
 
 
@@ -586,8 +586,9 @@ class ClnBlock(torch.autograd.Function):
         direct = all(t is not None for t in sk)       # FlatAdam: gradients go straight into the flat buffer
         if direct:
             _claim_sinks(w1)
-        # The second stream does not pay here (22.7 vs 22.3 ms/step at paper size): the 1024-thread cLN kernels fill
-        # every wave slot of a CU, so the weight gradients only time-slice with them.  CTN_CLN_SIDE=1 turns it on.
+        # Weight gradients on the second stream: with the round-1 weight-gradient kernel this lost (22.7 vs 22.3 ms/step: the
+        # 1024-thread cLN kernels fill every wave slot); with the w4 kernel and the 5 us slab reduce it wins, 20.07 vs
+        # 21.7 ms/step at paper size (CONFIG=causal benchmarks/ab_step.py).  CTN_CLN_SIDE=0 turns it off.
         side = direct and _SIDE_ENABLED and _CLN_SIDE
         dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
         if side:

@@ -795,3 +795,34 @@ def test_temporal_block_on_persistent_gemms(persistent_gemms, norm_type, causal,
 def test_tiny_model_on_persistent_gemms(persistent_gemms):
     """Whole model (composite stack: transposed weight copies + persistent kernels) against the reference fixture."""
     test_model_matches_reference_golden("model_tiny_gln")
+
+
+# ----------------------------------------------------------------------------- v_mfma_f32_16x16x4_f32 forms
+@pytest.fixture
+def mfma16_kernels():
+    """GEMM tile 11 (64x64 on v_mfma_f32_16x16x4_f32) and the 16x16x4 weight-gradient kernel for one test."""
+    ctn.lib.call("ctn_tune", b"pw_tile", 11)
+    ctn.lib.call("ctn_tune", b"wgrad_mf", 16)
+    yield
+    ctn.lib.call("ctn_tune", b"pw_tile", -1)
+    ctn.lib.call("ctn_tune", b"wgrad_mf", 32)
+    ops._ws_cache.clear()
+
+
+def test_mfma16_gemm_family_matches_fp64(mfma16_kernels):
+    for (M, R, Cn, K) in [(1, 128, 16, 64), (2, 32, 64, 799), (3, 132, 20, 130), (2, 256, 512, 515), (2, 512, 256, 1000)]:
+        for trans in (False, True):
+            test_pw_gemm_plain(M, R, Cn, K, trans)
+    test_pw_gemm_asymmetric_identity()
+    test_pw_gemm_relu_and_stats_and_prologue()
+    for case in [(2, 64, 64, 799), (3, 512, 256, 1300), (1, 132, 72, 300)]:
+        test_pw_wgrad(*case)
+
+
+@pytest.mark.parametrize("norm_type,causal,dil_x,K", [("gLN", False, 3, 799), ("gLN", True, 7, 1203)])
+def test_temporal_block_on_mfma16(mfma16_kernels, norm_type, causal, dil_x, K):
+    test_temporal_block_fwd_bwd(norm_type, causal, dil_x, K)
+
+
+def test_tiny_model_on_mfma16(mfma16_kernels):
+    test_model_matches_reference_golden("model_tiny_gln")
