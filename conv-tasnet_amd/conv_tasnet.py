@@ -226,13 +226,15 @@ class TemporalConvNet(nn.Module):
 
     def blocks(self, x, K):
         blks = [blk for rep in self.network[2] for blk in rep]
-        if ops.composite_enabled() and blks and all(b.norm_type == "gLN" for b in blks):
-            # the whole stack behind one C call per direction (ctn_tcn_gln_fwd / _bwd); bitwise the per-block path
+        norms = set(b.norm_type for b in blks)
+        if ops.composite_enabled() and blks and norms in ({"gLN"}, {"cLN"}):
+            # the whole stack behind one C call per direction (ctn_tcn_{gln,cln}_fwd / _bwd); bitwise the per-block path
             params = [p for b in blks for p in b.fused_params()]
             dil = [b.dilation for b in blks]
+            gln = norms == {"gLN"}
             if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-                return ops.TcnGln.apply(x, K, dil, blks[0].causal, *params)
-            return ops.tcn_gln_infer(x.contiguous(), K, dil, blks[0].causal, params)
+                return (ops.TcnGln if gln else ops.TcnCln).apply(x, K, dil, blks[0].causal, *params)
+            return (ops.tcn_gln_infer if gln else ops.tcn_cln_infer)(x.contiguous(), K, dil, blks[0].causal, params)
         for blk in blks:
             x = blk.fused(x, K)
         return x

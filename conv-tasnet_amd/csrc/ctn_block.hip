@@ -193,3 +193,140 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
 }
 
 }  // extern "C"
+
+// ---- cLN stack (causal BASELINE config): the same host-side composite over the un-fused norm kernels ------------------
+namespace {
+struct ClnBwdWs {
+    size_t dn2, dd, dn1, pcw, pcn, dap, slab, total, slab_bytes;
+};
+ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P) {
+    ClnBwdWs w;
+    size_t o = 0;
+    const size_t hsz = align256((size_t)M * H * Kp * sizeof(float));
+    w.dn2 = o; o += hsz;
+    w.dd = o; o += hsz;
+    w.dn1 = o; o += hsz;
+    w.pcw = o; o += align256((size_t)P * M * H * sizeof(float));
+    w.pcn = o; o += align256(ctn_cln_bwd_pc_floats(M, H, Kp) * sizeof(float));
+    w.dap = o; o += align256((size_t)ctn_cln_bwd_blocks(M, Kp) * sizeof(float));
+    const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
+    w.slab_bytes = s1 > s2 ? s1 : s2;
+    w.slab = o; o += align256(w.slab_bytes);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) {
+    (void)M; (void)Kp;
+    return (size_t)nblocks * 2 * align256((size_t)H * B * sizeof(float));      // [nblocks][w1^T | w2^T]
+}
+size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P) { return cln_bwd_ws(M, B, H, Kp, P).total; }
+
+int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
+                    float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && workspace, "ctn_tcn_cln_fwd: null pointer");
+    CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_fwd: bad sizes");
+    if (workspace_bytes < ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nblocks)) {
+        ctn_set_error("ctn_tcn_cln_fwd: workspace too small");
+        return CTN_ERR_WORKSPACE;
+    }
+    const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
+    float* const wt = (float*)workspace;
+    const size_t wsz = align256((size_t)H * B * sizeof(float)) / sizeof(float);
+    int rc;
+    {
+        std::vector<const void*> src(nblocks);
+        std::vector<void*> dst(nblocks);
+        for (int i = 0; i < nblocks; ++i) {
+            const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+            for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
+            src[i] = p[P_W1]; dst[i] = wt + (size_t)(2 * i) * wsz;
+        }
+        if ((rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, H, B, stream))) return rc;
+        for (int i = 0; i < nblocks; ++i) {
+            src[i] = ((const float* const*)(params + (size_t)i * NPARAM))[P_W2]; dst[i] = wt + (size_t)(2 * i + 1) * wsz;
+        }
+        if ((rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, B, H, stream))) return rc;
+    }
+    const float* x = x0;
+    for (int i = 0; i < nblocks; ++i) {
+        const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+        const size_t s = save ? (size_t)i : 0;
+        float* const h1 = h1s + s * hsz; float* const n1 = n1s + s * hsz; float* const d = ds + s * hsz; float* const n2 = n2s + s * hsz;
+        float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
+        float* const stb = st + s * 4 * ssz;
+        if ((rc = ctn_pw_gemm(wt + (size_t)(2 * i) * wsz, x, h1, M, H, B, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = ctn_cln_fwd(h1, n1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], stream))) return rc;
+        if ((rc = ctn_dw_fwd(n1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, stream))) return rc;
+        if ((rc = ctn_cln_fwd(d, n2, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], stream))) return rc;
+        if ((rc = ctn_pw_gemm(wt + (size_t)(2 * i + 1) * wsz, n2, out, M, B, H, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr,
+                              nullptr, x, nullptr, nullptr, 0, stream))) return rc;
+        x = out;
+    }
+    return CTN_OK;
+}
+
+int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
+                    const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
+                    const float* st, const float* dout, float* dxs, float* dh1s,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
+    CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && dout && dxs && dh1s && workspace,
+                "ctn_tcn_cln_bwd: null pointer");
+    CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_bwd: bad sizes");
+    const ClnBwdWs w = cln_bwd_ws(M, B, H, Kp, P);
+    if (workspace_bytes < w.total) {
+        ctn_set_error("ctn_tcn_cln_bwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+        return CTN_ERR_WORKSPACE;
+    }
+    char* const ws = (char*)workspace;
+    float* const dn2 = (float*)(ws + w.dn2);
+    float* const dd = (float*)(ws + w.dd);
+    float* const dn1 = (float*)(ws + w.dn1);
+    float* const pcw = (float*)(ws + w.pcw);
+    float* const pcn = (float*)(ws + w.pcn);
+    float* const dap = (float*)(ws + w.dap);
+    void* const slab = ws + w.slab;
+    const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
+    void* const wst = side_stream ? side_stream : stream;
+    int rc;
+    for (int i = nblocks - 1; i >= 0; --i) {
+        const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+        float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
+        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j] && g[j], "ctn_tcn_cln_bwd: block %d parameter / gradient %d is null", i, j);
+        const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
+        const float* const h1 = h1s + (size_t)i * hsz; const float* const n1 = n1s + (size_t)i * hsz;
+        const float* const d = ds + (size_t)i * hsz; const float* const n2 = n2s + (size_t)i * hsz;
+        const float* const stb = st + (size_t)i * 4 * ssz;
+        const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;
+        float* const dx = dxs + (size_t)i * xsz;
+        float* const dh1 = dh1s + (size_t)i * hsz;          // a slot per block: the side stream reads it while the chain moves on
+        if ((rc = ctn_pw_gemm(p[P_W2], dy, dn2, M, H, B, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, 0, stream))) return rc;
+        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        if ((rc = ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
+        if ((rc = ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap, pcn, stream))) return rc;
+        if ((rc = ctn_cln_bwd_finalize(pcn, dap, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], stream))) return rc;
+        if ((rc = ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream))) return rc;
+        if ((rc = ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], stream))) return rc;
+        if ((rc = ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap, pcn, stream))) return rc;
+        if ((rc = ctn_cln_bwd_finalize(pcn, dap, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], stream))) return rc;
+        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        if (side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
+        if ((rc = ctn_pw_gemm(p[P_W1], dh1, dx, M, B, H, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr,
+                              nullptr, 0, stream))) return rc;
+        if (!side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
+    }
+    if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;
+    return CTN_OK;
+}
+
+}  // extern "C"

@@ -206,10 +206,14 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
                 if constexpr (EPI == EPI_PRELU_STATS) {
-                    const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
-                    const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
-                    s1 += (p0 + p1) + (p2 + p3);
-                    s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+                    // rows >= R of an overhanging tile: exact zeros with TRANS_W = 0 (range-checked weight rows), but the NEXT
+                    // contraction row's values with TRANS_W = 1 -- their stores are dropped, the statistics must skip them
+                    if (r0 + wm * WM + mt * 32 + rl < a.R) {
+                        const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
+                        const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
+                        s1 += (p0 + p1) + (p2 + p3);
+                        s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+                    }
                 }
                 if constexpr (EPI == EPI_GLN_BWD) {
                     const float4 y = buf_ld4(rsAux, vo0, so);

@@ -732,11 +732,187 @@ __global__ __launch_bounds__(NTB) void cln_bwd_dx_reg_kernel(const float* __rest
     }
 }
 
-// per-(m,c) partial of dgamma = sum_k dOut*xh and dbeta = sum_k dOut ; pc[2][M][Ch]
+// ---------------------------------------------------------------------------
+// Round-2 channel-wise LayerNorm ("v4"): 16-byte accesses along frames and ONE backward pass.
+// A 512-thread workgroup owns 32 frames x all channels: thread t holds the frame quad q = t % 8 (frames 4q..4q+3) of channel
+// group g = t / 8, i.e. channels g, g + 64, ... (CPT per thread).  A wave instruction then moves 8 rows x 128 bytes with
+// 64 float4 accesses instead of 4-byte ones.  Per-frame sums over channels: three xor-shuffles over the 8 groups of a wave,
+// then 8 float4 partials through LDS.  The backward kernel also produces the parameter-gradient partials: dgamma / dbeta of
+// a channel over this workgroup's 32 frames (its 4 frames per thread, then three xor-shuffles over the 8 quads), written to
+// pc [2][blocks][Ch] and summed in fixed order by cln_bwd_finalize -- the separate cln_bwd_params pass (a third read of both
+// tensors) is gone.
+// ---------------------------------------------------------------------------
+constexpr int C4_NT = 512, C4_FR = 32, C4_NG = C4_NT / (C4_FR / 4);      // 64 channel groups
+
+__device__ __forceinline__ float4 quad_group_sum(float4 v) {              // sum over the 8 channel groups of a wave (lane bits 3..5)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+        v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+    }
+    return v;
+}
+// sum of `v` over all 64 channel groups of the workgroup, result for this thread's frame quad in every thread
+__device__ __forceinline__ float4 block_group_sum(float4 v, float4 (*sh)[C4_FR / 4], int wave, int q, int lane) {
+    v = quad_group_sum(v);
+    __syncthreads();                                 // sh may still be read by a previous call
+    if (lane < C4_FR / 4) sh[wave][q] = v;
+    __syncthreads();
+    float4 r = sh[0][q];
+#pragma unroll
+    for (int w = 1; w < C4_NT / 64; ++w) {
+        const float4 t = sh[w][q];
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+    }
+    return r;
+}
+
+template <int CPT>
+__global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restrict__ Y, float* __restrict__ Out,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                           int M, int Ch, int K, int Kp, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ alpha_p) {
+    __shared__ float4 sh[C4_NT / 64][C4_FR / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid & 7, g = tid >> 3;
+    const int kb = Kp / C4_FR;
+    const int m = blockIdx.x / kb, k0 = (blockIdx.x % kb) * C4_FR + 4 * q;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const size_t off = (size_t)m * Ch * Kp + k0;
+    float4 v[CPT];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + C4_NG * j;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < Ch) t = ld4(Y + off + (size_t)c * Kp);
+        if (has_a) { t.x = prelu_f(t.x, al); t.y = prelu_f(t.y, al); t.z = prelu_f(t.z, al); t.w = prelu_f(t.w, al); }
+        v[j] = t;
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    float4 mu = block_group_sum(s, sh, wave, q, lane);
+    const float inv = 1.f / (float)Ch;
+    mu.x *= inv; mu.y *= inv; mu.z *= inv; mu.w *= inv;
+    float4 d2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+        if (g + C4_NG * j < Ch) {
+            d2.x += (v[j].x - mu.x) * (v[j].x - mu.x); d2.y += (v[j].y - mu.y) * (v[j].y - mu.y);
+            d2.z += (v[j].z - mu.z) * (v[j].z - mu.z); d2.w += (v[j].w - mu.w) * (v[j].w - mu.w);
+        }
+    const float4 var = block_group_sum(d2, sh, wave, q, lane);
+    const float4 rs = make_float4(1.0f / sqrtf(var.x * inv + CTN_EPS), 1.0f / sqrtf(var.y * inv + CTN_EPS),
+                                  1.0f / sqrtf(var.z * inv + CTN_EPS), 1.0f / sqrtf(var.w * inv + CTN_EPS));
+    if (g == 0) {
+        *reinterpret_cast<float4*>(mean_o + (size_t)m * Kp + k0) = mu;
+        *reinterpret_cast<float4*>(rstd_o + (size_t)m * Kp + k0) = rs;
+    }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + C4_NG * j;
+        if (c < Ch) {
+            const float ga = gamma[c], be = beta[c];
+            float4 o;
+            o.x = k0 + 0 < K ? ga * ((v[j].x - mu.x) * rs.x) + be : 0.f;
+            o.y = k0 + 1 < K ? ga * ((v[j].y - mu.y) * rs.y) + be : 0.f;
+            o.z = k0 + 2 < K ? ga * ((v[j].z - mu.z) * rs.z) + be : 0.f;
+            o.w = k0 + 3 < K ? ga * ((v[j].w - mu.w) * rs.w) + be : 0.f;
+            *reinterpret_cast<float4*>(Out + off + (size_t)c * Kp) = o;
+        }
+    }
+}
+
+template <int CPT>
+__global__ __launch_bounds__(C4_NT) void cln_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                           float* __restrict__ dY, const float* __restrict__ mean_i,
+                                                           const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
+                                                           const float* __restrict__ gamma, const float* __restrict__ alpha_p,
+                                                           const float* __restrict__ add, const float* __restrict__ relu_ref,
+                                                           float* __restrict__ dalpha_part, float* __restrict__ pc) {
+    __shared__ float4 sh[C4_NT / 64][C4_FR / 4];
+    __shared__ float red[C4_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid & 7, g = tid >> 3;
+    const int kb = Kp / C4_FR, nblk = M * kb;
+    const int m = blockIdx.x / kb, k0 = (blockIdx.x % kb) * C4_FR + 4 * q;
+    const bool has_a = alpha_p != nullptr;
+    const float al = has_a ? alpha_p[0] : 1.f;
+    const size_t off = (size_t)m * Ch * Kp + k0;
+    const float4 mu = ld4(mean_i + (size_t)m * Kp + k0), rs = ld4(rstd_i + (size_t)m * Kp + k0);
+    const float vm[4] = {k0 + 0 < K ? 1.f : 0.f, k0 + 1 < K ? 1.f : 0.f, k0 + 2 < K ? 1.f : 0.f, k0 + 3 < K ? 1.f : 0.f};
+    float4 t[CPT], yv[CPT];           // gamma * dOut (0 for frames >= K) and the raw input of this thread's channels
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + C4_NG * j;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f), d = y;
+        float ga = 0.f;
+        if (c < Ch) {
+            y = ld4(Y + off + (size_t)c * Kp);
+            d = ld4(dOut + off + (size_t)c * Kp);
+            ga = gamma[c];
+        }
+        d.x *= vm[0]; d.y *= vm[1]; d.z *= vm[2]; d.w *= vm[3];
+        const float4 v = has_a ? make_float4(prelu_f(y.x, al), prelu_f(y.y, al), prelu_f(y.z, al), prelu_f(y.w, al)) : y;
+        const float4 xh = make_float4((v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w);
+        // parameter-gradient partials of channel c over this workgroup's frames: its 4 frames here, the 8 quads by shuffles
+        float pg = (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w), pb = (d.x + d.y) + (d.z + d.w);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64); }
+        if (q == 0 && c < Ch) {
+            pc[(size_t)blockIdx.x * Ch + c] = pg;
+            pc[((size_t)nblk + blockIdx.x) * Ch + c] = pb;
+        }
+        yv[j] = y;
+        t[j] = make_float4(ga * d.x, ga * d.y, ga * d.z, ga * d.w);
+        s1.x += t[j].x; s1.y += t[j].y; s1.z += t[j].z; s1.w += t[j].w;
+        s2.x += t[j].x * xh.x; s2.y += t[j].y * xh.y; s2.z += t[j].z * xh.z; s2.w += t[j].w * xh.w;
+    }
+    float4 m1 = block_group_sum(s1, sh, wave, q, lane), m2 = block_group_sum(s2, sh, wave, q, lane);
+    const float inv = 1.f / (float)Ch;
+    m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
+    m2.x *= inv; m2.y *= inv; m2.z *= inv; m2.w *= inv;
+    float dal = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = g + C4_NG * j;
+        if (c < Ch) {
+            const size_t o = off + (size_t)c * Kp;
+            const float yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w}, tt[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
+            const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+            const float a1[4] = {m1.x, m1.y, m1.z, m1.w}, a2[4] = {m2.x, m2.y, m2.z, m2.w};
+            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f), rf = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (add != nullptr) ad = ld4(add + o);
+            if (relu_ref != nullptr) rf = ld4(relu_ref + o);
+            const float av[4] = {ad.x, ad.y, ad.z, ad.w}, rv[4] = {rf.x, rf.y, rf.z, rf.w};
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = has_a ? prelu_f(yy[e], al) : yy[e];
+                const float xh = (v - mm[e]) * rr[e];
+                const float da = rr[e] * (tt[e] - a1[e] - xh * a2[e]);
+                float x = 0.f;
+                if (vm[e] != 0.f) {
+                    if (has_a && yy[e] < 0.f) dal += da * yy[e];
+                    x = (has_a && yy[e] < 0.f) ? al * da : da;
+                    x += av[e];
+                    if (!(rv[e] > 0.f)) x = 0.f;
+                }
+                r[e] = x;
+            }
+            *reinterpret_cast<float4*>(dY + o) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+    if (dalpha_part != nullptr) {
+        dal = block_sum<float, C4_NT>(dal, red);
+        if (tid == 0) dalpha_part[blockIdx.x] = dal;
+    }
+}
+
+// per-(m,c) partial of dgamma = sum_k dOut*xh and dbeta = sum_k dOut ; pc[2][rows][Ch], rows >= M (fallback of the v4 kernel)
 __global__ __launch_bounds__(NT) void cln_bwd_params_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                             int M, int Ch, int K, int Kp, const float* __restrict__ alpha_p,
-                                                            float* __restrict__ pc) {
+                                                            float* __restrict__ pc, int rows) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = (Ch + ROWS - 1) / ROWS;
     const int m = blockIdx.x / hb;
@@ -763,7 +939,7 @@ __global__ __launch_bounds__(NT) void cln_bwd_params_kernel(const float* __restr
     db = wave_sum(db);
     if (lane == 0) {
         pc[(size_t)m * Ch + c] = dg;
-        pc[(size_t)M * Ch + (size_t)m * Ch + c] = db;
+        pc[(size_t)rows * Ch + (size_t)m * Ch + c] = db;
     }
 }
 
@@ -826,10 +1002,11 @@ __global__ __launch_bounds__(NT) void dw_bwd_finalize_kernel(const float* __rest
     else db1[h] = s;
 }
 
-// Finish ctn_cln_bwd's partials in one launch: pc [2, M, Ch] -> dgamma[Ch], dbeta[Ch] (sum over m, thread per
-// channel); the last workgroup sums the nblk per-workgroup dalpha partials (fixed order).
+// Finish ctn_cln_bwd's partials in one launch: pc [2][rows][Ch] -> dgamma[Ch], dbeta[Ch]: one WAVE per output (f, c) sums its
+// `rows` partials in a fixed order (rows = workgroups of the backward kernel: 800 at the paper shape); the last workgroup
+// sums the nblk per-workgroup dalpha partials.
 __global__ __launch_bounds__(NT) void cln_bwd_finalize_kernel(const float* __restrict__ pc, const float* __restrict__ dap,
-                                                              int M, int Ch, int nblk, float* __restrict__ dgamma,
+                                                              int rows, int Ch, int nblk, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ dalpha) {
     __shared__ float red[NT / 64];
     if (blockIdx.x == gridDim.x - 1) {
@@ -840,12 +1017,23 @@ __global__ __launch_bounds__(NT) void cln_bwd_finalize_kernel(const float* __res
         if (threadIdx.x == 0) dalpha[0] = s;
         return;
     }
-    const int o = blockIdx.x * NT + threadIdx.x;
+    const int o = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (o >= 2 * Ch) return;
     const int f = o / Ch, c = o % Ch;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += pc[((size_t)f * M + m) * Ch + c];
-    (f == 0 ? dgamma : dbeta)[c] = s;
+    for (int r = lane; r < rows; r += 64) s += pc[((size_t)f * rows + r) * Ch + c];
+    s = wave_sum(s);
+    if (lane == 0) (f == 0 ? dgamma : dbeta)[c] = s;
+}
+
+// pc [P, M, H] (the un-fused ctn_dw_bwd's tap partials) -> dD [H, P], summed over m in a fixed order
+__global__ __launch_bounds__(NT) void dw_bwd_taps_kernel(const float* __restrict__ pc, int P, int M, int H, float* __restrict__ dD) {
+    const int o = blockIdx.x * NT + threadIdx.x;
+    if (o >= P * H) return;
+    const int j = o / H, h = o % H;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += pc[((size_t)j * M + m) * H + h];
+    dD[(size_t)h * P + j] = s;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -962,6 +1150,13 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
     return CTN_OK;
 }
 
+int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* stream) {
+    CTN_REQUIRE(pc && dD && P >= 1 && P <= MAXP && M > 0 && H > 0, "ctn_dw_bwd_taps: bad arguments");
+    hipLaunchKernelGGL(dw_bwd_taps_kernel, dim3((unsigned)ctn_cdiv(P * H, NT)), dim3(NT), 0, (hipStream_t)stream, pc, P, M, H, dD);
+    CTN_CHECK_LAUNCH("ctn_dw_bwd_taps");
+    return CTN_OK;
+}
+
 int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
                       const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
                       float* dalpha_part, void* stream) {
@@ -985,11 +1180,27 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
     return CTN_OK;
 }
 
+static bool cln_v4_ok(int Ch, int Kp, const void* a, const void* b, const void* c) {
+    return Ch <= 8 * C4_NG && Kp % C4_FR == 0 && aligned16(a) && aligned16(b) && aligned16(c);
+}
+
 int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int Ch, int K, int Kp,
                 const float* gamma, const float* beta, const float* alpha, void* stream) {
     CTN_REQUIRE(Y && Out && mean && rstd && gamma && beta, "ctn_cln_fwd: null pointer");
     CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K, "ctn_cln_fwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
+    if (cln_v4_ok(Ch, Kp, Y, Out, mean) && aligned16(rstd)) {     // 16-byte accesses along frames (round 2)
+        const dim3 grid((unsigned)(M * (Kp / C4_FR)));
+#define CTN_CLN_FWD4(CPT_) hipLaunchKernelGGL((cln_fwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha)
+        const int cpt = ctn_cdiv(Ch, C4_NG);
+        if (cpt <= 1) CTN_CLN_FWD4(1);
+        else if (cpt <= 2) CTN_CLN_FWD4(2);
+        else if (cpt <= 4) CTN_CLN_FWD4(4);
+        else CTN_CLN_FWD4(8);
+#undef CTN_CLN_FWD4
+        CTN_CHECK_LAUNCH("ctn_cln_fwd");
+        return CTN_OK;
+    }
     const dim3 grid_r((unsigned)(M * ctn_cdiv(Kp, CLN_FR)));
 #define CTN_CLN_FWD(CPT_) hipLaunchKernelGGL((cln_fwd_reg_kernel<CLN_FR, CPT_>), grid_r, dim3(CLN_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha)
     const int cpt = ctn_cdiv(Ch, CLN_NT / CLN_FR);
@@ -1005,9 +1216,10 @@ int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int
     return CTN_OK;
 }
 
-int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, CLN_FR); }   // >= the generic kernel's M * ceil(Kp/64)
+int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, CLN_FR); }   // workgroups of the backward kernels (32 frames each)
+size_t ctn_cln_bwd_pc_floats(int M, int Ch, int Kp) { return (size_t)2 * ctn_cln_bwd_blocks(M, Kp) * Ch; }
 
-// dalpha_part: [ctn_cln_bwd_blocks] (only when alpha != NULL); pc: [2, M, Ch]
+// see include/ctn_hip.h.  pc is [2][ctn_cln_bwd_blocks(M, Kp)][Ch]
 int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
                 int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
                 const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream) {
@@ -1016,14 +1228,28 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     CTN_REQUIRE(!alpha || dalpha_part, "ctn_cln_bwd: dalpha_part required with alpha");
     CTN_REQUIRE(aligned16(dOut) && aligned16(Y) && aligned16(mean) && aligned16(rstd), "ctn_cln_bwd: alignment");
     hipStream_t st = (hipStream_t)stream;
-    // parameter partials first: dY may alias dOut
-    hipLaunchKernelGGL(cln_bwd_params_kernel, dim3((unsigned)(M * ctn_cdiv(Ch, ROWS))), dim3(NT), 0, st,
-                       dOut, Y, mean, rstd, M, Ch, K, Kp, alpha, pc);
-    CTN_CHECK_LAUNCH("ctn_cln_bwd/params");
-    const dim3 grid_r((unsigned)(M * ctn_cdiv(Kp, CLN_FR)));
     float* const dap = alpha ? dalpha_part : nullptr;
-    // <= 16 channels per thread keeps the kernel at ~100 VGPRs: 512-thread workgroups (two per CU) up to 256 channels,
-    // 1024-thread ones up to 512; wider layers take the generic kernel.
+    const int rows = ctn_cln_bwd_blocks(M, Kp);
+    if (cln_v4_ok(Ch, Kp, dOut, Y, dY) && (!add || aligned16(add)) && (!relu_ref || aligned16(relu_ref))) {
+        // one pass: input gradient AND the parameter-gradient partials (dY may alias dOut: each thread reads its elements
+        // of dOut before it writes them)
+        const dim3 grid((unsigned)rows);
+#define CTN_CLN_BWD4(CPT_) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc)
+        const int cpt = ctn_cdiv(Ch, C4_NG);
+        if (cpt <= 1) CTN_CLN_BWD4(1);
+        else if (cpt <= 2) CTN_CLN_BWD4(2);
+        else if (cpt <= 4) CTN_CLN_BWD4(4);
+        else CTN_CLN_BWD4(8);
+#undef CTN_CLN_BWD4
+        CTN_CHECK_LAUNCH("ctn_cln_bwd");
+        return CTN_OK;
+    }
+    // fallback (very wide layers / unaligned frames): parameter partials first (dY may alias dOut), into the first M rows of pc
+    hipMemsetAsync(pc, 0, sizeof(float) * ctn_cln_bwd_pc_floats(M, Ch, Kp), st);
+    hipLaunchKernelGGL(cln_bwd_params_kernel, dim3((unsigned)(M * ctn_cdiv(Ch, ROWS))), dim3(NT), 0, st,
+                       dOut, Y, mean, rstd, M, Ch, K, Kp, alpha, pc, rows);
+    CTN_CHECK_LAUNCH("ctn_cln_bwd/params");
+    const dim3 grid_r((unsigned)rows);
 #define CTN_CLN_BWD(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_dx_reg_kernel<CLN_FR, CPT_, NTB_>), grid_r, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap)
     if (Ch <= 32) CTN_CLN_BWD(2, 512);
     else if (Ch <= 64) CTN_CLN_BWD(4, 512);
@@ -1031,7 +1257,7 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     else if (Ch <= 256) CTN_CLN_BWD(16, 512);
     else if (Ch <= 512) CTN_CLN_BWD(16, 1024);
     else {      // generic kernel; it fills only the first M*ceil(Kp/64) partials of the buffer
-        if (dap) hipMemsetAsync(dap, 0, sizeof(float) * (size_t)ctn_cln_bwd_blocks(M, Kp), st);
+        if (dap) hipMemsetAsync(dap, 0, sizeof(float) * (size_t)rows, st);
         hipLaunchKernelGGL(cln_bwd_dx_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st, dOut, Y, dY, mean, rstd, M,
                            Ch, K, Kp, gamma, alpha, add, relu_ref, dap);
     }
@@ -1044,14 +1270,14 @@ int ctn_cln_bwd_finalize(const float* pc, const float* dalpha_part, int M, int C
                          float* dalpha, void* stream) {
     CTN_REQUIRE(pc && dgamma && dbeta && M > 0 && Ch > 0 && Kp > 0, "ctn_cln_bwd_finalize: bad arguments");
     CTN_REQUIRE(!dalpha_part || dalpha, "ctn_cln_bwd_finalize: dalpha required with dalpha_part");
-    const unsigned nb = (unsigned)ctn_cdiv(2 * Ch, NT) + 1;
-    hipLaunchKernelGGL(cln_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, dalpha_part, M, Ch,
-                       ctn_cln_bwd_blocks(M, Kp), dgamma, dbeta, dalpha);
+    const int rows = ctn_cln_bwd_blocks(M, Kp);
+    const unsigned nb = (unsigned)ctn_cdiv(2 * Ch, NT / 64) + 1;
+    hipLaunchKernelGGL(cln_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, dalpha_part, rows, Ch, rows,
+                       dgamma, dbeta, dalpha);
     CTN_CHECK_LAUNCH("ctn_cln_bwd_finalize");
     return CTN_OK;
 }
 
-// out[f][i] = sum_r in[f][r][i]
 int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void* stream) {
     CTN_REQUIRE(in && out && F > 0 && Mid > 0 && Inner > 0, "ctn_reduce_mid: bad arguments");
     const long long n = (long long)F * Inner;

@@ -271,7 +271,7 @@ def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None, sinks
     gradient views): the fixed-order finishing reductions then write there directly and None is returned for them."""
     M, Ch, Kp = Y.shape
     dY = torch.empty_like(Y)
-    pc = torch.empty((2, M, Ch), dtype=F32, device=Y.device)
+    pc = torch.empty((lib.ctn_cln_bwd_pc_floats(M, Ch, Kp),), dtype=F32, device=Y.device)
     dap = None
     if alpha is not None:
         dap = torch.empty((lib.ctn_cln_bwd_blocks(M, Kp),), dtype=F32, device=Y.device)
@@ -547,6 +547,89 @@ class TcnGln(torch.autograd.Function):
                  0 if side is None else side.cuda_stream)
         ctx.acts = None             # release 4 GB of saved activations as soon as they are consumed
         # the call joined the side stream into the current one, so stream-ordered reuse of these buffers is safe
+        if direct:
+            return (dxs[0], None, None, None) + (None,) * len(params)
+        return (dxs[0], None, None, None) + tuple(gdst)
+
+
+def tcn_cln_infer(x0, K, dilations, causal, params):
+    """cLN stack without saving activations (torch.no_grad paths)."""
+    nb = len(dilations)
+    M, B, Kp = x0.shape
+    H, P = params[0].shape[0], params[4].shape[-1]
+    dev = x0.device
+    _chk(x0, *params)
+    xs = torch.empty((2, M, B, Kp), dtype=F32, device=dev)
+    h = torch.empty((4, M, H, Kp), dtype=F32, device=dev)
+    st = torch.empty((4, M, Kp), dtype=F32, device=dev)
+    nbytes = lib.ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nb)
+    ws = _workspace(nbytes, dev, "tcn_cln_fwd")
+    dil = (ctypes.c_int * nb)(*dilations)
+    lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h[0]), _p(h[1]), _p(h[2]), _p(h[3]), _p(st), 0,
+             M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+    return xs[(nb - 1) & 1]
+
+
+class TcnCln(torch.autograd.Function):
+    """The stack of cLN TemporalBlocks (causal BASELINE config) as one autograd node over ctn_tcn_cln_fwd / _bwd: the
+    kernels and their order are ClnBlock's, issued from C++ (bitwise the per-kernel path)."""
+
+    @staticmethod
+    def forward(ctx, x0, K, dilations, causal, *params):
+        nb = len(dilations)
+        if len(params) != nb * NPARAM:
+            raise ValueError("TcnCln: expected %d parameter tensors, got %d" % (nb * NPARAM, len(params)))
+        x0 = _c(x0)
+        M, B, Kp = x0.shape
+        H, P = params[0].shape[0], params[4].shape[-1]
+        if H % 4 or B % 4:
+            raise ValueError("HIP path needs B and H to be multiples of 4")
+        dev = x0.device
+        _chk(x0, *params)
+        xs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
+        hs = torch.empty((4, nb, M, H, Kp), dtype=F32, device=dev)          # h1, n1, d, n2
+        st = torch.empty((nb, 4, M, Kp), dtype=F32, device=dev)            # mean1, rstd1, mean2, rstd2
+        nbytes = lib.ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nb)
+        ws = _workspace(nbytes, dev, "tcn_cln_fwd")
+        dil = (ctypes.c_int * nb)(*dilations)
+        lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]), _p(hs[3]), _p(st), 1,
+                 M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+        ctx.acts = (x0, xs, hs, st)
+        ctx.params = params
+        ctx.cfg = (K, dil, nb, causal, P)
+        ctx.sinks = tuple(_sink(p) for p in params)
+        return xs[nb - 1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, xs, hs, st = ctx.acts
+        params = ctx.params
+        K, dil, nb, causal, P = ctx.cfg
+        dout = _c(dout)
+        _, M, B, Kp = xs.shape
+        H = hs.shape[3]
+        dev = x0.device
+        _chk(dout)
+        direct = all(s is not None for s in ctx.sinks)
+        if direct:
+            _claim_sinks(params[0])
+            gdst = ctx.sinks
+        else:
+            sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+            flat = torch.empty((sum(sizes),), dtype=F32, device=dev)
+            gdst, o = [], 0
+            for p, n in zip(params, sizes):
+                gdst.append(flat[o:o + p.numel()].view(p.shape))
+                o += n
+        dxs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
+        dh1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
+        nbytes = lib.ctn_tcn_cln_bwd_workspace(M, B, H, Kp, P)
+        ws = _workspace(nbytes, dev, "tcn_cln_bwd")
+        side = _side_stream(dev) if (direct and _SIDE_ENABLED and _CLN_SIDE) else None
+        lib.call("ctn_tcn_cln_bwd", _ptr_table(params), _ptr_table(gdst), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]),
+                 _p(hs[3]), _p(st), _p(dout), _p(dxs), _p(dh1s), M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(),
+                 0 if side is None else side.cuda_stream)
+        ctx.acts = None
         if direct:
             return (dxs[0], None, None, None) + (None,) * len(params)
         return (dxs[0], None, None, None) + tuple(gdst)

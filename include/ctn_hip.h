@@ -123,6 +123,9 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
                         float* dgamma1, float* dbeta1, float* dalpha2, const float* dalpha1_part, int n_dalpha1,
                         float* dalpha1, void* stream);
 
+/* Fixed-order finish of the UN-fused ctn_dw_bwd's tap partials: pc [P, M, H] -> dD [H, P] (the depthwise weight's layout). */
+int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* stream);
+
 /* dY = rstd*(gamma*dN - S1/n - xhat*S2/n) * prelu'(Y);  dalpha_part [M*H] = per-row sum over Y<0 of (..)*Y.
  * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN. */
 int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
@@ -167,17 +170,36 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P);
 
+/* The same for a stack of cLN TemporalBlocks (norm_type = 'cLN': the causal BASELINE config), un-fused norms: per block
+ * forward  1x1 -> cLN(PReLU) -> depthwise -> cLN(PReLU) -> 1x1 + residual,  backward the adjoint chain with the two weight
+ * gradients on side_stream.  Saved by forward (slot per block): xs [nblocks][M,B,Kp]; h1s, n1s, ds, n2s [nblocks][M,H,Kp]
+ * (1x1 output, first norm output, depthwise output, second norm output); st [nblocks][4][M,Kp] = mean1, rstd1, mean2, rstd2.
+ * save = 0: two x slots, one slot of everything else.  backward scratch: dxs [nblocks][M,B,Kp], dh1s [nblocks][M,H,Kp]. */
+int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
+                    float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks);
+int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
+                    const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
+                    const float* st, const float* dout, float* dxs, float* dh1s,
+                    int M, int B, int H, int K, int Kp, int P, int causal,
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
+size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P);
+
 /* ---- channel-wise LayerNorm, src/conv_tasnet.py:313-335 (per frame, biased variance) -----
  * Out = gamma*((a-mean_k)*rstd_k)+beta with a = prelu(Y,alpha) if alpha != NULL else Y.
  * mean, rstd: [M,Kp] saved for backward. */
 int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int Ch, int K, int Kp,
                 const float* gamma, const float* beta, const float* alpha, void* stream);
-/* dY = [cLN/PReLU backward of dOut  (+ add)] masked by (relu_ref > 0) when relu_ref != NULL.
- * pc [2, M, Ch]: per-(m,c) partials of dgamma, dbeta;  dalpha_part [ctn_cln_bwd_blocks(M,Kp)]. */
+/* dY = [cLN/PReLU backward of dOut  (+ add)] masked by (relu_ref > 0) when relu_ref != NULL -- and, in the same pass, the
+ * parameter-gradient partials: pc [2][ctn_cln_bwd_blocks(M,Kp)][Ch] (ctn_cln_bwd_pc_floats() floats: dgamma, dbeta of every
+ * 32-frame workgroup) and dalpha_part [ctn_cln_bwd_blocks(M,Kp)]; ctn_cln_bwd_finalize sums them in fixed order. */
 int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
                 int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
                 const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream);
 int ctn_cln_bwd_blocks(int M, int Kp);
+size_t ctn_cln_bwd_pc_floats(int M, int Ch, int Kp);
 /* One launch that finishes the partials above in fixed order: dgamma[Ch], dbeta[Ch] from pc, and dalpha[1] from
  * dalpha_part [ctn_cln_bwd_blocks(M,Kp)] when that is non-NULL. */
 int ctn_cln_bwd_finalize(const float* pc, const float* dalpha_part, int M, int Ch, int Kp, float* dgamma, float* dbeta,

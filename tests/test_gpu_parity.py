@@ -762,7 +762,13 @@ def test_persistent_gemm_family_matches_fp64(persistent_gemms):
             test_pw_gemm_plain(M, R, Cn, K, trans)
     test_pw_gemm_asymmetric_identity()
     test_pw_gemm_relu_and_stats_and_prologue()
-    # forward forms on a transposed weight copy (the fast operand form), R = 40 overhangs the 64-row tile
+    _forward_forms_on_transposed_weights()
+
+
+def _forward_forms_on_transposed_weights():
+    """K1 / K3 forms of ctn_pw_gemm on a transposed weight copy (trans_w = 1 + statistics epilogue / gLN prologue + residual):
+    what the composite stack launches.  R = 40 overhangs the 64-row tile: with trans_w = 1 the overhanging accumulator rows
+    hold the next contraction row's values, which the statistics must not see."""
     M, B, H, K = 3, 24, 40, 1203
     Kp = ops.padded_frames(K)
     x = pad(torch.randn(M, B, K, generator=g(4)), Kp).to(DEV)
@@ -785,6 +791,11 @@ def test_persistent_gemm_family_matches_fp64(persistent_gemms):
     assert rel_err(out2[..., :K], ref2) < 5e-6
     assert float(out2[..., K:].abs().max()) == 0.0
     np.testing.assert_allclose(ms[:, 0].cpu().numpy(), p.mean((1, 2)).numpy(), rtol=1e-5, atol=1e-6)
+
+
+
+def test_forward_forms_on_transposed_weights_default_family():
+    _forward_forms_on_transposed_weights()
 
 
 @pytest.mark.parametrize("norm_type,causal,dil_x,K", [("gLN", False, 3, 799), ("gLN", True, 7, 1203), ("cLN", True, 2, 3700)])
@@ -817,6 +828,7 @@ def test_mfma16_gemm_family_matches_fp64(mfma16_kernels):
     test_pw_gemm_relu_and_stats_and_prologue()
     for case in [(2, 64, 64, 799), (3, 512, 256, 1300), (1, 132, 72, 300)]:
         test_pw_wgrad(*case)
+    _forward_forms_on_transposed_weights()
 
 
 @pytest.mark.parametrize("norm_type,causal,dil_x,K", [("gLN", False, 3, 799), ("gLN", True, 7, 1203)])

@@ -228,8 +228,9 @@ def test_graphed_backprop_replays_the_eager_step():
 
 @pytest.mark.parametrize("flat", [True, False])
 @pytest.mark.parametrize("causal", [False, True])
-def test_composite_stack_is_bitwise_the_per_kernel_path(flat, causal, monkeypatch):
-    """ctn_tcn_gln_fwd / ctn_tcn_gln_bwd (one C call per direction for the whole TemporalBlock stack, weight gradients on
+@pytest.mark.parametrize("norm_type", ["gLN", "cLN"])
+def test_composite_stack_is_bitwise_the_per_kernel_path(flat, causal, norm_type, monkeypatch):
+    """ctn_tcn_{gln,cln}_fwd / _bwd (one C call per direction for the whole TemporalBlock stack, weight gradients on
     the second stream) against the per-kernel entry points driven block by block from Python: outputs, loss and every
     gradient must be bitwise equal -- the composite only moves the host side of the launches into C++."""
     from conv_tasnet_amd import ops
@@ -238,7 +239,7 @@ def test_composite_stack_is_bitwise_the_per_kernel_path(flat, causal, monkeypatc
     for composite in (True, False):
         monkeypatch.setattr(ops, "_COMPOSITE", composite)
         torch.manual_seed(3)
-        m = ctn.ConvTasNet(32, 20, 16, 32, 3, 4, 2, 2, norm_type="gLN", causal=causal).to(DEV)
+        m = ctn.ConvTasNet(32, 20, 16, 32, 3, 4, 2, 2, norm_type=norm_type, causal=causal).to(DEV)
         opt = FlatAdam(m.parameters(), lr=1e-3) if flat else None
         if opt is not None:
             opt.zero_grad()
