@@ -753,6 +753,7 @@ __device__ __forceinline__ float4 quad_group_sum(float4 v) {              // sum
     return v;
 }
 // sum of `v` over all 64 channel groups of the workgroup, result for this thread's frame quad in every thread
+template <int NW = C4_NT / 64>
 __device__ __forceinline__ float4 block_group_sum(float4 v, float4 (*sh)[C4_FR / 4], int wave, int q, int lane) {
     v = quad_group_sum(v);
     __syncthreads();                                 // sh may still be read by a previous call
@@ -760,7 +761,7 @@ __device__ __forceinline__ float4 block_group_sum(float4 v, float4 (*sh)[C4_FR /
     __syncthreads();
     float4 r = sh[0][q];
 #pragma unroll
-    for (int w = 1; w < C4_NT / 64; ++w) {
+    for (int w = 1; w < NW; ++w) {
         const float4 t = sh[w][q];
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
     }
@@ -822,15 +823,19 @@ __global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restri
     }
 }
 
-template <int CPT>
-__global__ __launch_bounds__(C4_NT) void cln_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+// NTB threads = NTB/8 channel groups.  CPT = 8 at 512 threads needs 161 VGPRs (one workgroup = 2 waves per SIMD) and is
+// still the fastest form for 512 channels: 1024 threads x CPT 4 (4 waves per SIMD) measured 84 us against 55 us, capping
+// the registers at 128 (re-reading dOut in the second phase) 59 us.
+template <int CPT, int NTB>
+__global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                            float* __restrict__ dY, const float* __restrict__ mean_i,
                                                            const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
                                                            const float* __restrict__ gamma, const float* __restrict__ alpha_p,
                                                            const float* __restrict__ add, const float* __restrict__ relu_ref,
                                                            float* __restrict__ dalpha_part, float* __restrict__ pc) {
-    __shared__ float4 sh[C4_NT / 64][C4_FR / 4];
-    __shared__ float red[C4_NT / 64];
+    constexpr int NW = NTB / 64, NG = NTB / (C4_FR / 4);
+    __shared__ float4 sh[NW][C4_FR / 4];
+    __shared__ float red[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid & 7, g = tid >> 3;
     const int kb = Kp / C4_FR, nblk = M * kb;
     const int m = blockIdx.x / kb, k0 = (blockIdx.x % kb) * C4_FR + 4 * q;
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(C4_NT) void cln_bwd_v4_kernel(const float* __restri
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int c = g + C4_NG * j;
+        const int c = g + NG * j;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f), d = y;
         float ga = 0.f;
         if (c < Ch) {
@@ -867,14 +872,14 @@ __global__ __launch_bounds__(C4_NT) void cln_bwd_v4_kernel(const float* __restri
         s1.x += t[j].x; s1.y += t[j].y; s1.z += t[j].z; s1.w += t[j].w;
         s2.x += t[j].x * xh.x; s2.y += t[j].y * xh.y; s2.z += t[j].z * xh.z; s2.w += t[j].w * xh.w;
     }
-    float4 m1 = block_group_sum(s1, sh, wave, q, lane), m2 = block_group_sum(s2, sh, wave, q, lane);
+    float4 m1 = block_group_sum<NW>(s1, sh, wave, q, lane), m2 = block_group_sum<NW>(s2, sh, wave, q, lane);
     const float inv = 1.f / (float)Ch;
     m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
     m2.x *= inv; m2.y *= inv; m2.z *= inv; m2.w *= inv;
     float dal = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int c = g + C4_NG * j;
+        const int c = g + NG * j;
         if (c < Ch) {
             const size_t o = off + (size_t)c * Kp;
             const float yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w}, tt[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(C4_NT) void cln_bwd_v4_kernel(const float* __restri
         }
     }
     if (dalpha_part != nullptr) {
-        dal = block_sum<float, C4_NT>(dal, red);
+        dal = block_sum<float, NTB>(dal, red);
         if (tid == 0) dalpha_part[blockIdx.x] = dal;
     }
 }
@@ -1002,13 +1007,15 @@ __global__ __launch_bounds__(NT) void dw_bwd_finalize_kernel(const float* __rest
     else db1[h] = s;
 }
 
-// Finish ctn_cln_bwd's partials in one launch: pc [2][rows][Ch] -> dgamma[Ch], dbeta[Ch]: one WAVE per output (f, c) sums its
-// `rows` partials in a fixed order (rows = workgroups of the backward kernel: 800 at the paper shape); the last workgroup
-// sums the nblk per-workgroup dalpha partials.
+// Finish ctn_cln_bwd's partials in one launch: pc [2][rows][Ch] -> dgamma[Ch], dbeta[Ch].  A workgroup owns 64 channels of one
+// of the two outputs: lanes along channels (256-byte coalesced rows), the four waves take rows w, w+4, ... and their sums are
+// added in wave order (fixed order: bitwise reproducible).  rows = workgroups of the backward kernel (800 at the paper shape).
+// The last workgroup sums the nblk per-workgroup dalpha partials.
 __global__ __launch_bounds__(NT) void cln_bwd_finalize_kernel(const float* __restrict__ pc, const float* __restrict__ dap,
                                                               int rows, int Ch, int nblk, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ dalpha) {
     __shared__ float red[NT / 64];
+    __shared__ float part[NT / 64][64];
     if (blockIdx.x == gridDim.x - 1) {
         if (dap == nullptr) return;
         float s = 0.f;
@@ -1017,13 +1024,25 @@ __global__ __launch_bounds__(NT) void cln_bwd_finalize_kernel(const float* __res
         if (threadIdx.x == 0) dalpha[0] = s;
         return;
     }
-    const int o = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (o >= 2 * Ch) return;
-    const int f = o / Ch, c = o % Ch;
+    const int cb = (Ch + 63) / 64;
+    const int f = blockIdx.x / cb, c = (blockIdx.x % cb) * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
     float s = 0.f;
-    for (int r = lane; r < rows; r += 64) s += pc[((size_t)f * rows + r) * Ch + c];
-    s = wave_sum(s);
-    if (lane == 0) (f == 0 ? dgamma : dbeta)[c] = s;
+    if (c < Ch) {
+        const float* __restrict__ p = pc + (size_t)f * rows * Ch + c;
+        int r = wave;
+        for (; r + 28 < rows; r += 32) {                 // eight independent loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(r + 4 * j) * Ch];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; r < rows; r += 4) s += p[(size_t)r * Ch];
+    }
+    part[wave][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (wave == 0 && c < Ch)
+        (f == 0 ? dgamma : dbeta)[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
 
 // pc [P, M, H] (the un-fused ctn_dw_bwd's tap partials) -> dD [H, P], summed over m in a fixed order
@@ -1234,12 +1253,11 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
         // one pass: input gradient AND the parameter-gradient partials (dY may alias dOut: each thread reads its elements
         // of dOut before it writes them)
         const dim3 grid((unsigned)rows);
-#define CTN_CLN_BWD4(CPT_) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc)
-        const int cpt = ctn_cdiv(Ch, C4_NG);
-        if (cpt <= 1) CTN_CLN_BWD4(1);
-        else if (cpt <= 2) CTN_CLN_BWD4(2);
-        else if (cpt <= 4) CTN_CLN_BWD4(4);
-        else CTN_CLN_BWD4(8);
+#define CTN_CLN_BWD4(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, NTB_>), grid, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc)
+        if (Ch <= C4_NG) CTN_CLN_BWD4(1, C4_NT);
+        else if (Ch <= 2 * C4_NG) CTN_CLN_BWD4(2, C4_NT);
+        else if (Ch <= 4 * C4_NG) CTN_CLN_BWD4(4, C4_NT);
+        else CTN_CLN_BWD4(8, C4_NT);
 #undef CTN_CLN_BWD4
         CTN_CHECK_LAUNCH("ctn_cln_bwd");
         return CTN_OK;
@@ -1271,7 +1289,7 @@ int ctn_cln_bwd_finalize(const float* pc, const float* dalpha_part, int M, int C
     CTN_REQUIRE(pc && dgamma && dbeta && M > 0 && Ch > 0 && Kp > 0, "ctn_cln_bwd_finalize: bad arguments");
     CTN_REQUIRE(!dalpha_part || dalpha, "ctn_cln_bwd_finalize: dalpha required with dalpha_part");
     const int rows = ctn_cln_bwd_blocks(M, Kp);
-    const unsigned nb = (unsigned)ctn_cdiv(2 * Ch, NT / 64) + 1;
+    const unsigned nb = (unsigned)(2 * ctn_cdiv(Ch, 64)) + 1;
     hipLaunchKernelGGL(cln_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, dalpha_part, rows, Ch, rows,
                        dgamma, dbeta, dalpha);
     CTN_CHECK_LAUNCH("ctn_cln_bwd_finalize");
