@@ -840,8 +840,24 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 
 }  // namespace
 
+#include "ctn_gemm_b3.h"            // the split-bf16 ("b3") arithmetic of the same GEMMs
+
 int g_ctn_tile_override = -2;
 extern int g_ctn_block_wt;          // ctn_block.hip
+
+// GEMM arithmetic: 0 = fp32 MFMA (bit-exact fp32 FMA chains), 1 = "b3" (two bf16 pieces per operand, three bf16 MFMAs,
+// fp32 accumulation: ctn_gemm_b3.h).  CTN_GEMM_ARITH=fp32|b3, ctn_tune("arith", 0|1).  Layers with fewer than 64 output
+// rows (the decoder's basis GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
+static int g_arith = -1;
+static bool arith_b3() {
+    if (g_arith < 0) {
+        const char* e = getenv("CTN_GEMM_ARITH");
+        g_arith = (e && !strcmp(e, "fp32")) ? 0 : 1;
+    }
+    return g_arith == 1;
+}
+static bool b3_fwd(int R) { return arith_b3() && R >= 64; }
+static bool b3_wgrad(int R, int Cn) { return arith_b3() && R >= 32 && Cn >= 32; }
 
 template <typename TL>
 static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd,
@@ -997,7 +1013,14 @@ int ctn_tune_pw_tile(int id) {
 // internal (ctn_block.hip): 1 when the persistent kernels are active, i.e. fused prologue / statistics work with trans_w = 1
 int ctn_pw_uses_pk(void) { return use_pk() ? 1 : 0; }
 
+int ctn_gemm_arith(void) { return arith_b3() ? 1 : 0; }
+
 int ctn_pw_stats_parts(int M, int R, int Kp) {
+    if (b3_fwd(R)) {
+        int tm, tn;
+        ctn_b3_tile_dims(&tm, &tn);
+        return ctn_cdiv(R, tm) * ctn_cdiv(Kp, tn);
+    }
     if (use_pk()) return ctn_cdiv(R, 64) * ctn_cdiv(Kp, 64) * 4;      // >= one partial per wave of every tile (64x64 tiles: exactly)
     int tm, tn;
     tile_dims(pick_tile(M, R, Kp), &tm, &tn);
@@ -1022,7 +1045,10 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
     a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
-    if (use_pk()) {
+    if (b3_fwd(R)) {
+        ctn_b3_launch_fwd(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
+                          (hipStream_t)stream);
+    } else if (use_pk()) {
         rc = launch_pk(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
                        (hipStream_t)stream);
         if (rc) return rc;
@@ -1047,7 +1073,9 @@ int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R,
     a.store_f32 = 1;
     a.W = W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
-    if (use_pk()) {
+    if (b3_fwd(R)) {
+        ctn_b3_launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
+    } else if (use_pk()) {
         rc = launch_pk(a, 1, false, false, false, false, true, (hipStream_t)stream);
         if (rc) return rc;
     } else {
@@ -1102,6 +1130,9 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "block_wt")) g_ctn_block_wt = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_mf") && (value == 16 || value == 32)) g_w4_mf = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
+    else if (!strcmp(key, "arith") && (value == 0 || value == 1)) g_arith = value;
+    else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 3) g_ctn_b3_tile = value;
+    else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }
@@ -1115,6 +1146,10 @@ int ctn_tune_wgrad(int tile, int blocks) {
 
 size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp) {
     int tile, chunk, cpm;
+    if (b3_wgrad(R, Cn)) {
+        ctn_b3_wgrad_plan(M, R, Cn, Kp, &chunk, &cpm);
+        return (size_t)M * cpm * R * Cn * sizeof(float);
+    }
     wgrad_plan(M, R, Cn, Kp, &tile, &chunk, &cpm);
     return (size_t)M * cpm * R * Cn * sizeof(float);
 }
@@ -1128,6 +1163,21 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     CTN_REQUIRE(!pro_ms || (pro_gamma && pro_beta && pro_alpha), "ctn_pw_wgrad: incomplete prologue arguments");
     WgArgs a{};
     a.dOut = dOut; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.pro_gamma = pro_gamma; a.pro_beta = pro_beta; a.pro_alpha = pro_alpha; a.pro_ms = pro_ms;
+    if (b3_wgrad(R, Cn)) {
+        ctn_b3_wgrad_plan(M, R, Cn, Kp, &a.chunk, &a.chunks_per_m);
+        const size_t need = (size_t)M * a.chunks_per_m * R * Cn * sizeof(float);
+        if (workspace == nullptr || workspace_bytes < need) {
+            ctn_set_error("ctn_pw_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+            return CTN_ERR_WORKSPACE;
+        }
+        const int ns = ctn_b3_launch_wgrad(a, pro_ms != nullptr, (hipStream_t)stream);
+        CTN_CHECK_LAUNCH("ctn_pw_wgrad");
+        const long long nn = (long long)R * Cn;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);
+        CTN_CHECK_LAUNCH("ctn_pw_wgrad/reduce");
+        return CTN_OK;
+    }
     int wt;
     wgrad_plan(M, R, Cn, Kp, &wt, &a.chunk, &a.chunks_per_m);
     int wtm, wtn;

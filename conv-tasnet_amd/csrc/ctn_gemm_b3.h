@@ -1,0 +1,395 @@
+// "b3" arithmetic of the 1x1-convolution GEMMs: fp32 operands multiplied on the bf16 matrix cores as TWO bf16 pieces each.
+//
+//   a = a_hi + a_lo + ra,   a_hi = bf16_rne(a),  a_lo = bf16_rne(a - a_hi)   (a - a_hi is exact in fp32; |ra| <= 2^-18 |a|)
+//   a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi         (dropped: a_lo.b_lo and the remainders, each <= 2^-18 |a.b| -- the
+//                                                     products carry >= 16 significand bits, accumulation is fp32)
+//
+// Each piece-product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (8 x 8-bit significands).  Why: the
+// training step runs AT the 1400 W package power cap, so its time is its energy.  A 6.7-GFLOP
+// launch of the fp32-MFMA kernels costs 80-90 mJ (58-72 us under the cap), the same launch as three bf16 MFMAs per
+// 16-deep step 54-67 mJ (40-48 us) with the round-1 kernel structure (profiles/r02_d_power_lab_split.txt): the bf16
+// MFMA costs a tenth of the fp32 one per FLOP, and it overlaps the VALU work of the other waves on its SIMD, which
+// the fp32 MFMA does not.  Accuracy: the whole-model SI-SNR moves by ~1e-4 dB (budget 1e-3, tests/test_gpu_parity.py).
+// CTN_GEMM_ARITH=fp32 / ctn_tune("arith", 0) selects the bit-exact fp32-MFMA kernels of ctn_gemm.hip instead.
+//
+// Same contracts as the fp32 kernels (PwArgs / WgArgs, prologues, epilogues, tile order, fixed-order reductions): both
+// operands are split on the fly while they are staged global -> registers -> LDS, so no entry point changes and no
+// pre-split copies exist in HBM.  Operands whose contraction index is strided in memory (activations [channel][frame],
+// weights given as [contraction][row]) are stored channel-major in LDS and read with ds_read_b64_tr_b16, the hardware
+// transposing read; operands with a contiguous contraction (stored [row][contraction] weights, both operands of the
+// weight gradient) are stored row-major and read with ds_read_b128.
+// Included by ctn_gemm.hip (the argument structs live in that translation unit's anonymous namespace).
+#pragma once
+#include "ctn_gemm_common.h"
+
+namespace {
+
+constexpr int XK = 32;               // contraction steps per k-tile (two MFMA steps of depth 16)
+constexpr int XPA = XK + 8;          // row pitch of a row-major piece plane in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
+
+// four consecutive fp32 -> the two bf16x4 pieces (round-to-nearest-even both times)
+__device__ __forceinline__ void split2x4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    hi = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    lo = bf16x4{(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
+}
+
+template <typename TL, int TRANS_W>
+struct B3 {
+    static constexpr int PB = TL::TN + 32;                                   // pitch of a channel-major plane row in bf16
+    static constexpr int PA = TL::TM + 32;
+    static constexpr int A_ELEMS = TRANS_W ? 2 * XK * PA : 2 * TL::TM * XPA;  // bf16 elements, both pieces
+    static constexpr int B_ELEMS = 2 * XK * PB;
+    static constexpr int MAIN_BYTES = (A_ELEMS + B_ELEMS) * 2;
+    static constexpr int STAGE_BYTES = TL::STAGE_FLOATS * 4;
+    static constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
+};
+
+typedef bf16x4 __attribute__((address_space(3))) * lds_b4;
+
+// 8 contraction steps (k = 8 * (lane / 32) .. + 7 of a 16-deep MFMA step) of column `lane % 32` of a 32-column tile,
+// out of a channel-major plane (row = contraction index, pitch P): two transposing reads of 4 rows each.
+// Lane map of ds_read_b64_tr_b16: the 16-lane group g = lane / 16 covers columns 16 (g & 1) .. + 15 and rows
+// 8 (g / 2) .. + 7 of the 16 x 32 block; lane 4 q + p of a group addresses row q, columns 4 p .. 4 p + 3.
+__device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane_at_tile, int P, int lane) {
+    const int tr_q = (lane >> 2) & 3, tr_f = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const __bf16* base = plane_at_tile + ((lane >> 5) * 8 + tr_q) * P + tr_f;
+    const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base));
+    const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base + 4 * P));
+    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <typename TL, int TRANS_W, int PRO, int EPI>
+__global__ __launch_bounds__(TL::NTH, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192) ? 3 : 2))
+void pw_gemm_b3_kernel(PwArgs a) {
+    constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, NTH = TL::NTH;
+    using L = B3<TL, TRANS_W>;
+    constexpr int PB = L::PB, PA = L::PA;
+    constexpr int B_L = XK * TN / 4 / NTH, A_L = XK * TM / 4 / NTH;         // float4 loads per thread per k-tile
+    constexpr int AT = XK / 4;                                              // threads per stored weight row (TRANS_W = 0)
+    static_assert(A_L >= 1 && B_L >= 1, "tile too small for the workgroup");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[L::SMEM_BYTES];
+    __shared__ double red[NTH / 64];
+    __bf16* const Ap = reinterpret_cast<__bf16*>(smem_raw);        // TRANS_W: [2][XK][PA]   else [2][TM][XPA]
+    __bf16* const Bp = Ap + L::A_ELEMS;                            // [2][XK][PB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WGN, wn = wave % TL::WGN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c;
+    const int m = bid / a.tiles_c;
+    const int r0 = rt * TM, c0 = ct * TN;
+    const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        finalize_stats<NTH>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts, (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
+        p_alpha = a.pro_alpha[0];
+        if (a.pro_ms_out != nullptr && rt == 0 && ct == 0 && tid == 0) {
+            a.pro_ms_out[2 * m] = p_mean;
+            a.pro_ms_out[2 * m + 1] = p_rstd;
+        }
+    }
+    const int nk = (a.Cn + XK - 1) / XK;
+    // Buffer loads: contraction rows past Cn of W^T / X / gamma / beta fall off the end of their buffer and read 0 (the
+    // k-tile offset is part of the per-lane offset, so the range check sees it).  TRANS_W = 0 with Cn % 32 != 0 reads
+    // the next weight row instead: finite values against all-zero activation rows.  Rows / columns that overhang R / Kp
+    // are never stored (and skipped by the statistics).
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)a.R * (unsigned)a.Cn * 4u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
+    __amdgpu_buffer_rsrc_t rsG = rsX, rsBt = rsX;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        rsG = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
+        rsBt = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
+    }
+    int voA[A_L], voB[B_L], voP[B_L];
+#pragma unroll
+    for (int j = 0; j < A_L; ++j) {
+        if constexpr (TRANS_W == 0) voA[j] = ((r0 + tid / AT + (NTH / AT) * j) * a.Cn + (tid % AT) * 4) * 4;
+        else voA[j] = ((tid / (TM / 4) + (4 * NTH / TM) * j) * a.R + r0 + (tid % (TM / 4)) * 4) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_L; ++j) {
+        const int i = tid / (TN / 4) + (4 * NTH / TN) * j;
+        voB[j] = (i * a.Kp + c0 + (tid % (TN / 4)) * 4) * 4;
+        voP[j] = i * 4;
+    }
+    const int sA = (TRANS_W == 0 ? XK : XK * a.R) * 4, sB = XK * a.Kp * 4;      // byte steps per k-tile
+
+    auto load_tile = [&](int kt, float4 (&ra)[A_L], float4 (&rb)[B_L], float2 (&rp)[B_L]) {
+#pragma unroll
+        for (int j = 0; j < A_L; ++j) ra[j] = buf_ld4(rsW, voA[j] + kt * sA, 0);
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            rb[j] = buf_ld4(rsX, voB[j] + kt * sB, 0);
+            if constexpr (PRO == PRO_PRELU_NORM)
+                rp[j] = make_float2(buf_ld1(rsG, voP[j] + kt * XK * 4, 0), buf_ld1(rsBt, voP[j] + kt * XK * 4, 0));
+            else
+                rp[j] = make_float2(0.f, 0.f);
+        }
+    };
+    // split while writing to LDS (after the prologue): the global loads have no consumer before the MFMA phase they overlap
+    auto store_tile = [&](const float4 (&ra)[A_L], const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
+#pragma unroll
+        for (int j = 0; j < A_L; ++j) {
+            bf16x4 hi, lo;
+            split2x4(ra[j], hi, lo);
+            if constexpr (TRANS_W == 0) {
+                const int r = tid / AT + (NTH / AT) * j, c = (tid % AT) * 4;
+                *reinterpret_cast<bf16x4*>(Ap + r * XPA + c) = hi;
+                *reinterpret_cast<bf16x4*>(Ap + (TM + r) * XPA + c) = lo;
+            } else {
+                const int c = tid / (TM / 4) + (4 * NTH / TM) * j, r = (tid % (TM / 4)) * 4;
+                *reinterpret_cast<bf16x4*>(Ap + c * PA + r) = hi;
+                *reinterpret_cast<bf16x4*>(Ap + (XK + c) * PA + r) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            const int i = tid / (TN / 4) + (4 * NTH / TN) * j, k = (tid % (TN / 4)) * 4;
+            float4 v = rb[j];
+            if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
+            bf16x4 hi, lo;
+            split2x4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(Bp + i * PB + k) = hi;
+            *reinterpret_cast<bf16x4*>(Bp + (XK + i) * PB + k) = lo;
+        }
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < XK / 16; ++ks) {
+            bf16x8 af[MT][2], bfr[NTL][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if constexpr (TRANS_W == 0)
+                        af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * TM + wm * WM + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                    else
+                        af[i][p] = frag_tr(Ap + (p * XK + ks * 16) * PA + wm * WM + i * 32, PA, lane);
+                }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bfr[j][p] = frag_tr(Bp + (p * XK + ks * 16) * PB + wn * WN + j * 32, PB, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {      // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // One LDS buffer, two barriers per k-tile; the global loads of the next k-tile wait in registers.  Other resident
+    // workgroups of the CU fill the barrier gaps (2-4 per CU).
+    float4 pa[A_L], pb[B_L];
+    float2 pp[B_L];
+    load_tile(0, pa, pb, pp);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile(pa, pb, pp);
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1, pa, pb, pp);
+        compute();
+        __syncthreads();
+    }
+    gemm_epilogue<TL, EPI>(a, acc, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient: dW[r,c] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  Both operands have the contraction (frames) contiguous:
+// row-major piece planes, ds_read_b128 fragments.  128 x 128 output tile per 256-thread workgroup (each wave 64 x 64),
+// split over (utterance, frame chunk) into fp32 slabs summed in fixed order by slab_reduce_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int PRO>
+__global__ __launch_bounds__(NT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * BM * XPA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * BN * XPA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c; bid /= a.tiles_c;
+    const int sp = bid;
+    const int m = sp / a.chunks_per_m, ch = sp % a.chunks_per_m;
+    const int kb = ch * a.chunk;
+    const int ke = min(kb + a.chunk, a.Kp);
+    const int r0 = rt * BM, c0 = ct * BN;
+    const float* __restrict__ Gm = a.dOut + (size_t)m * a.R * a.Kp;
+    const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        p_mean = a.pro_ms[2 * m];
+        p_rstd = a.pro_ms[2 * m + 1];
+        p_alpha = a.pro_alpha[0];
+    }
+    // staging map: 8 threads per row (32 frames = 8 float4), 32 rows per pass, 4 passes for 128 rows.  Rows past R / Cn
+    // fall off the end of the utterance's matrix and read 0; frames past the chunk end are masked by the per-lane offset.
+    const __amdgpu_buffer_rsrc_t rsG = make_rsrc(Gm, (unsigned)a.R * (unsigned)a.Kp * 4u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
+    float4 ra[4], rb[4];
+    float2 rg[4];
+    if constexpr (PRO == PRO_PRELU_NORM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + (tid >> 3) + 32 * j;
+            rg[j] = c < a.Cn ? make_float2(a.pro_gamma[c], a.pro_beta[c]) : make_float2(0.f, 0.f);
+        }
+    }
+    const int nk = (ke - kb + XK - 1) / XK;
+    const int kq = (tid & 7) * 4;
+    auto load_regs = [&](int kt) {
+        const int k = kb + kt * XK + kq;
+        const unsigned oob = k < ke ? 0u : 0x80000000u;  // past the chunk: push the offset out of range -> reads 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (tid >> 3) + 32 * j;
+            ra[j] = buf_ld4(rsG, (int)((unsigned)(((r0 + row) * a.Kp + k) * 4) + oob), 0);
+            rb[j] = buf_ld4(rsX, (int)((unsigned)(((c0 + row) * a.Kp + k) * 4) + oob), 0);
+        }
+    };
+    auto write_one = [&](__bf16* P, int row, const float4& v) {
+        bf16x4 hi, lo;
+        split2x4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(P + row * XPA + kq) = hi;
+        *reinterpret_cast<bf16x4*>(P + (BM + row) * XPA + kq) = lo;
+    };
+    auto write_lds = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (tid >> 3) + 32 * j;
+            write_one(Ap, row, ra[j]);
+            float4 x = rb[j];
+            // (frames past the chunk end are frames >= Kp >= K: the prologue zeroes them like every frame >= K)
+            if constexpr (PRO == PRO_PRELU_NORM) x = pro_apply(x, kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
+            write_one(Bp, row, x);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if (nk > 0) load_regs(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        write_lds(kt);
+        __syncthreads();
+        if (kt + 1 < nk) load_regs(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * BM + wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                    bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bp + (p * BN + wn * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = r0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int c = c0 + wn * 64 + nt * 32 + l31;
+                if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = acc[mt][nt][e];
+            }
+        }
+}
+
+template <typename TL>
+void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    else if (trans_w) {
+        if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else if (pro) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+        else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+        else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+    } else if (pro) {
+        if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+}
+
+}  // namespace
+
+// ---- host side, used by the entry points of ctn_gemm.hip ---------------------------------------------------------
+static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64   (ctn_tune("b3_tile", id)); in-step A/B: 12.0 / 11.5 / - / 12.0 ms
+static int g_ctn_b3_wgrad_blocks = 512;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
+
+static void ctn_b3_tile_dims(int* tm, int* tn) {
+    static const int d[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    *tm = d[g_ctn_b3_tile][0];
+    *tn = d[g_ctn_b3_tile][1];
+}
+
+static void ctn_b3_launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    int tm, tn;
+    ctn_b3_tile_dims(&tm, &tn);
+    a.tiles_r = ctn_cdiv(a.R, tm);
+    a.tiles_c = ctn_cdiv(a.Kp, tn);
+    switch (g_ctn_b3_tile) {
+        case 1: launch_b3_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 2: launch_b3_tile<T64x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 3: launch_b3_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        default: launch_b3_tile<T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+    }
+}
+
+static void ctn_b3_wgrad_plan(int M, int R, int Cn, int Kp, int* chunk, int* chunks_per_m) {
+    const int tiles = ctn_cdiv(R, BM) * ctn_cdiv(Cn, BN);
+    int cpm = ctn_cdiv(g_ctn_b3_wgrad_blocks, tiles * M);
+    const int max_cpm = ctn_cdiv(Kp, 256);         // keep >= 256 frames of contraction per slab
+    if (cpm > max_cpm) cpm = max_cpm;
+    if (cpm < 1) cpm = 1;
+    const int c = ctn_cdiv(ctn_cdiv(Kp, cpm), XK) * XK;
+    *chunk = c;
+    *chunks_per_m = ctn_cdiv(Kp, c);
+}
+
+// a.chunk / a.chunks_per_m / a.slab already set by the caller from ctn_b3_wgrad_plan; returns the number of slabs
+static int ctn_b3_launch_wgrad(WgArgs& a, bool pro, hipStream_t st) {
+    a.tiles_r = ctn_cdiv(a.R, BM);
+    a.tiles_c = ctn_cdiv(a.Cn, BN);
+    const int nsplit = a.M * a.chunks_per_m;
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(NT);
+    if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_PRELU_NORM>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_NONE>), grid, block, 0, st, a);
+    return nsplit;
+}

@@ -30,14 +30,19 @@ constexpr int XAT = XK / 8;       // threads per 16-byte-chunked weight row
 #define CTN_X6_PF 2
 #endif
 constexpr int X6_PF = CTN_X6_PF;
+#ifdef CTN_X3      // energy experiment: two pieces per operand, three products (a1b1 + a1b2 + a2b1), error <= 2^-16 |ab|
+constexpr int NPL = 2;
+#else
+constexpr int NPL = 3;
+#endif
 constexpr int XPA = XK + 8;       // A-plane row pitch in bf16 (80 B / 144 B: conflict-free ds_read_b128 over 16 rows)
 constexpr int WXK = 32, WXPA = 40;   // weight-gradient kernel: 32 frames per k-tile
 
 template <typename TL>
 struct X6 {
     static constexpr int PB = TL::TN + 32;                          // B-plane row pitch in bf16 (TN*2 + 64 B)
-    static constexpr int A_ELEMS = 3 * TL::TM * XPA;                // bf16 elements
-    static constexpr int B_ELEMS = 3 * XK * PB;
+    static constexpr int A_ELEMS = NPL * TL::TM * XPA;                // bf16 elements
+    static constexpr int B_ELEMS = NPL * XK * PB;
     static constexpr int MAIN_BYTES = (A_ELEMS + B_ELEMS) * 2;
     static constexpr int STAGE_BYTES = TL::STAGE_FLOATS * 4;
     static constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
@@ -111,7 +116,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (a_ok[j]) v = *reinterpret_cast<const uint4*>(a_src[j] + p * plane + kc);
                 ra[p][j] = v;
@@ -135,7 +140,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
         for (int j = 0; j < A_L; ++j) {
             const int r = tid / XAT + AR * j, c = (tid % XAT) * 8;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = ra[p][j];
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4*>(Ap + (p * TM + r) * XPA + c) = ra[p][j];
         }
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
@@ -146,7 +151,7 @@ void pw_gemm_x6_kernel(X6Args xa) {
             split3x4(v, q1, q2, q3);
             *reinterpret_cast<bf16x4*>(Bp + (0 * XK + i) * PB + k) = q1;
             *reinterpret_cast<bf16x4*>(Bp + (1 * XK + i) * PB + k) = q2;
-            *reinterpret_cast<bf16x4*>(Bp + (2 * XK + i) * PB + k) = q3;
+            if constexpr (NPL == 3) *reinterpret_cast<bf16x4*>(Bp + (2 * XK + i) * PB + k) = q3;
         }
     };
 
@@ -171,12 +176,12 @@ void pw_gemm_x6_kernel(X6Args xa) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NPL; ++p)
                 af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * TM + wm * WM + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
 #pragma unroll
         for (int j = 0; j < NTL; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
                 const __bf16* base = Bp + (p * XK + ks * 16 + lhi * 8 + tr_q) * PB + wn * WN + j * 32 + tr_f;
                 const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base));
                 const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(base + 4 * PB));
@@ -186,9 +191,11 @@ void pw_gemm_x6_kernel(X6Args xa) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
+                if constexpr (NPL == 3) {
                 lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], lo[i][j], 0, 0, 0);
                 lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], lo[i][j], 0, 0, 0);
                 lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], lo[i][j], 0, 0, 0);
+                }
                 lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], lo[i][j], 0, 0, 0);
                 lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], lo[i][j], 0, 0, 0);
                 hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], hi[i][j], 0, 0, 0);
@@ -688,8 +695,8 @@ __global__ __launch_bounds__(NT) void split_bf16_kernel(const float* __restrict_
 
 template <int PRO>
 __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ap[3 * BM * WXPA];
-    __shared__ __attribute__((aligned(16))) __bf16 Bp[3 * BN * WXPA];
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * BM * WXPA];
+    __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * BN * WXPA];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bid = blockIdx.x;
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
         split3x4(v, q1, q2, q3);
         *reinterpret_cast<bf16x4*>(P + (0 * BM + row) * WXPA + kq) = q1;
         *reinterpret_cast<bf16x4*>(P + (1 * BM + row) * WXPA + kq) = q2;
-        *reinterpret_cast<bf16x4*>(P + (2 * BM + row) * WXPA + kq) = q3;
+        if constexpr (NPL == 3) *reinterpret_cast<bf16x4*>(P + (2 * BM + row) * WXPA + kq) = q3;
     };
     auto write_lds = [&](int kt) {
         const int kq = (tid & 7) * 4;
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NPL; ++p) {
                     af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * BM + wm * 64 + i * 32 + l31) * WXPA + ks * 16 + lhi * 8);
                     bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bp + (p * BN + wn * 64 + i * 32 + l31) * WXPA + ks * 16 + lhi * 8);
                 }
@@ -779,9 +786,11 @@ __global__ __launch_bounds__(NT) void pw_wgrad_x6_kernel(WgArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if constexpr (NPL == 3) {
                     lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], lo[i][j], 0, 0, 0);
                     lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], lo[i][j], 0, 0, 0);
                     lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], lo[i][j], 0, 0, 0);
+                    }
                     lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], lo[i][j], 0, 0, 0);
                     lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], lo[i][j], 0, 0, 0);
                     hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], hi[i][j], 0, 0, 0);

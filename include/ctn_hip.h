@@ -89,6 +89,14 @@ int ctn_tune_wgrad(int tile, int blocks);
  * CTN_PW_KERNEL / CTN_PK_WGS / CTN_WGRAD_KERNEL / CTN_WGRAD_BLOCKS environment variables set at first use).  Change them
  * only between steps (workspace sizes and statistics layouts depend on them). */
 int ctn_tune(const char* key, int value);
+/* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
+ *   1 = "b3": every fp32 operand is split into two bf16 pieces (round-to-nearest-even) and a.b is formed from the three
+ *       piece-products of weight >= 2^-9 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- products carry >= 16
+ *       significand bits; whole-model SI-SNR within ~1e-4 dB of the fp32 path (budget 1e-3 dB);
+ *   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains.
+ * Selected by CTN_GEMM_ARITH=b3|fp32 at first use or ctn_tune("arith", 0|1) between steps; layers with fewer than 64
+ * output rows always use the fp32 kernels. */
+int ctn_gemm_arith(void);
 
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
