@@ -31,7 +31,9 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)" (154.5 measured on the box:
                                # benchmarks/mfma_probe.hip, profiles/r02_a_mfma_probe.txt)
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0          # same guide, HBM3E peak
+ARITH = {"name": "b3"}         # GEMM arithmetic of this run (--arith): "b3" = 3 bf16 MFMAs per product step, "fp32" = fp32 MFMA
 PER_GPU_BATCH = 8
 CONFIGS = {
     "paper": dict(model=dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2), norm_type="gLN", causal=False, T=32000, sr=8000,
@@ -169,31 +171,64 @@ def _family(name, a):
             "ctn_dw_bwd_finalize": "dw_bwd_finalize (fixed-order parameter-gradient sums)"}.get(name, name), "hbm", None
 
 
+def _gemm_bytes(name, a, K):
+    """Algorithmic HBM bytes of one GEMM launch: every operand / result tensor once (weights are negligible)."""
+    M, R, Cn = a[3], a[4], a[5]
+    t = 4.0 * M * K
+    if name == "ctn_pw_gemm":
+        return t * (Cn + R + (R if a[15] else 0))                 # X, Out, residual
+    if name == "ctn_pw_dgrad_gln":
+        return t * (Cn + 2 * R)                                   # dOut, dN, y
+    return t * (R + Cn)                                           # weight gradient: both activations
+
+
 def family_table(probe, cfg, K, steps):
+    """Per kernel family: launches, in-step time, and the roofline that binds it.  A GEMM family is priced against BOTH
+    roofs -- executed MFMA FLOPs (3 bf16 MFMAs per algorithmic product step under b3, 1 fp32 MFMA under fp32) over the
+    dense peak of that MFMA type, and algorithmic bytes over 8 TB/s -- and reports the binding (larger) bound."""
     c = cfg["model"]
     M, H = PER_GPU_BATCH, c["H"]
     hbm_bytes = {"ctn_dw_fwd": 2, "ctn_dw_bwd": 4, "ctn_gln_prelu_bwd": 3}      # tensors of M*H*K*4 bytes read + written
+    b3 = ARITH["name"] == "b3"
     fams = {}
     for name, a, e0, e1 in probe:
         fam, bound, shape = _family(name, a)
-        f = fams.setdefault(fam, {"bound": bound, "us": [], "work": 0.0, "entry": name})
+        f = fams.setdefault(fam, {"bound": bound, "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": name})
         f["us"].append(1e3 * e0.elapsed_time(e1))
         if bound == "mfma":
-            f["work"] += 2.0 * shape[1] * shape[2] * K * shape[0]            # algorithmic FLOPs: 2*R*Cn per frame
+            f["flops"] += 2.0 * shape[1] * shape[2] * K * shape[0]           # algorithmic FLOPs: 2*R*Cn per frame
+            f["bytes"] += _gemm_bytes(name, a, K)
+            small = (shape[1] < 32 or shape[2] < 32) if name == "ctn_pw_wgrad" else shape[1] < 64
+            f["b3"] += int(b3 and not small)                                 # the library's rule (ctn_gemm.hip: b3_fwd / b3_wgrad)
         elif name in hbm_bytes:
-            f["work"] += hbm_bytes[name] * 4.0 * M * H * K                   # algorithmic bytes
+            f["bytes"] += hbm_bytes[name] * 4.0 * M * H * K                  # algorithmic bytes
     rows = []
     for fam, f in fams.items():
         tot = sum(f["us"])
-        row = {"family": fam, "bound": f["bound"], "launches_per_step": round(len(f["us"]) / steps, 1),
-               "us_per_launch": round(tot / len(f["us"]), 2), "ms_per_step": round(tot / steps / 1e3, 3)}
-        if f["work"] > 0:
-            rate = f["work"] / (tot * 1e-6)
-            if f["bound"] == "mfma":
-                row.update(achieved=round(rate / 1e12, 2), unit="TFLOP/s", frac=round(rate / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        n = len(f["us"])
+        row = {"family": fam, "bound": f["bound"], "launches_per_step": round(n / steps, 1),
+               "us_per_launch": round(tot / n, 2), "ms_per_step": round(tot / steps / 1e3, 3)}
+        if f["flops"] > 0:
+            on_b3 = f["b3"] * 2 > n
+            peak = PEAK_BF16_MFMA_TFLOPS if on_b3 else PEAK_F32_MFMA_TFLOPS
+            mfma_flops = f["flops"] * (3 if on_b3 else 1)                    # executed MFMA FLOPs
+            t_mfma, t_hbm = mfma_flops / (peak * 1e12), f["bytes"] / (PEAK_HBM_GBS * 1e9)
+            row["arith"] = "b3 (3 x v_mfma_f32_32x32x16_bf16 per 16-deep step)" if on_b3 else "fp32 (v_mfma_f32_32x32x2_f32)"
+            row["algorithmic_tflops"] = round(f["flops"] / (tot * 1e-6) / 1e12, 2)
+            row["mfma_floor_us"] = round(t_mfma / n * 1e6, 2)
+            row["hbm_floor_us"] = round(t_hbm / n * 1e6, 2)
+            if t_hbm >= t_mfma:
+                rate = f["bytes"] / (tot * 1e-6)
+                row.update(bound="hbm", achieved=round(rate / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS, frac=round(rate / 1e9 / PEAK_HBM_GBS, 4),
+                           work_per_launch=f["bytes"] / n)
             else:
-                row.update(achieved=round(rate / 1e9, 1), unit="GB/s", frac=round(rate / 1e9 / PEAK_HBM_GBS, 4))
-            row["work_per_launch"] = f["work"] / len(f["us"])
+                rate = mfma_flops / (tot * 1e-6)
+                row.update(bound="mfma", achieved=round(rate / 1e12, 2), unit="TFLOP/s", peak=peak, frac=round(rate / 1e12 / peak, 4),
+                           work_per_launch=mfma_flops / n)
+        elif f["bytes"] > 0:
+            rate = f["bytes"] / (tot * 1e-6)
+            row.update(achieved=round(rate / 1e9, 1), unit="GB/s", peak=PEAK_HBM_GBS, frac=round(rate / 1e9 / PEAK_HBM_GBS, 4),
+                       work_per_launch=f["bytes"] / n)
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
@@ -202,17 +237,17 @@ def family_table(probe, cfg, K, steps):
 def roofline(rows, probe_steps):
     dom = rows[0]
     traffic, src = None, None
-    for pmc in ("r02_pmc_wgrad_dW1.json", "r02_pmc_wgrad_dW2_pro.json"):      # PMC passes of the two weight-gradient kernels
-        path = os.path.join(ROOT, "profiles", pmc)
-        if os.path.exists(path):
-            try:
-                j = json.load(open(path))
-                if j.get("family", "")[:2] == dom["family"][:2]:
-                    traffic, src = j.get("hbm_bytes_per_launch"), "profiles/" + pmc
-            except Exception:
-                pass
+    for pmc in sorted(os.listdir(os.path.join(ROOT, "profiles"))):      # PMC passes (benchmarks/pmc_traffic.sh): family + arithmetic must match
+        if not (pmc.startswith("r02_pmc_") and pmc.endswith(".json")):
+            continue
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+            if j.get("family", "")[:2] == dom["family"][:2] and j.get("arith", "fp32") == ARITH["name"]:
+                traffic, src = j.get("hbm_bytes_per_launch"), "profiles/" + pmc
+        except Exception:
+            pass
     return {"bound": dom["bound"], "kernel": dom["family"], "achieved": dom.get("achieved"),
-            "peak": PEAK_F32_MFMA_TFLOPS if dom["bound"] == "mfma" else PEAK_HBM_GBS, "unit": dom.get("unit"),
+            "peak": dom.get("peak"), "unit": dom.get("unit"),
             "frac": dom.get("frac"), "us_per_launch": dom["us_per_launch"], "launches_per_step": dom["launches_per_step"],
             "work_per_launch": dom.get("work_per_launch"), "traffic": traffic, "traffic_source": src,
             "how": "largest total time among the kernel families of %d extra training steps after the timed region, each "
@@ -227,6 +262,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="paper")
+    ap.add_argument("--arith", choices=["b3", "fp32"], default=os.environ.get("CTN_GEMM_ARITH", "b3"),
+                    help="GEMM arithmetic: b3 = two bf16 pieces per fp32 operand on the bf16 matrix cores (library default), "
+                         "fp32 = fp32-MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CTN_BENCH_GRAPH", "0")),
@@ -246,6 +284,8 @@ def main():
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
+    ARITH["name"] = args.arith
+    ctn.lib.call("ctn_tune", b"arith", 1 if args.arith == "b3" else 0)
     torch.manual_seed(0)
     model = ctn.ConvTasNet(**cfg["model"], norm_type=cfg["norm_type"], causal=cfg["causal"], mask_nonlinear="relu").to(device)
     opt = FlatAdam(model.parameters(), lr=1e-3)
@@ -303,7 +343,9 @@ def main():
         out = {
             "metric": "4s 8kHz 2-spk utterances/sec (fwd+bwd)", "value": round(value, 2), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GEMM products from two bf16 pieces per operand, f32 accumulate)" if args.arith == "b3" else "f32",
+            "gemm_arith": args.arith, "data": "synthetic",
             "config": {"workload": (cfg["name"] % PER_GPU_BATCH) + " utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam",
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": cfg["T"],
                        "parallelism": "dp%d" % world},

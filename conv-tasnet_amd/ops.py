@@ -49,6 +49,36 @@ def gemm_mode():
     return _GEMM_MODE
 
 
+def gemm_arith():
+    """'b3' (default: two bf16 pieces per fp32 operand, three bf16 MFMAs, fp32 accumulation) or 'fp32' (fp32-MFMA kernels)."""
+    return "b3" if lib.ctn_gemm_arith() else "fp32"
+
+
+def set_gemm_arith(name):
+    """Select the arithmetic of every 1x1-convolution GEMM (include/ctn_hip.h: ctn_gemm_arith).  Change it between steps
+    only: statistics layouts and workspace sizes depend on it (the cached workspaces are dropped here)."""
+    if name not in ("b3", "fp32"):
+        raise ValueError("gemm arithmetic must be 'b3' or 'fp32'")
+    lib.call("ctn_tune", b"arith", 1 if name == "b3" else 0)
+    _ws_cache.clear()
+
+
+class gemm_arithmetic:
+    """with ops.gemm_arithmetic('fp32'): ...   -- forward AND backward of the enclosed steps on that arithmetic."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = gemm_arith()
+        set_gemm_arith(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        set_gemm_arith(self.prev)
+        return False
+
+
 def _split_planes(W, rows, cols, transpose):
     """[3][R][Cnp] bf16 planes of a weight matrix (W^T when transpose)."""
     R, Cn = (cols, rows) if transpose else (rows, cols)

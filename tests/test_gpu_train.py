@@ -9,7 +9,7 @@ import torch
 from conftest import load_golden
 from oracle import ctn_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_arith")]     # every test under both GEMM arithmetics (conftest.py)
 
 import conv_tasnet_amd as ctn  # noqa: E402
 from conv_tasnet_amd.optim import FlatAdam  # noqa: E402
