@@ -93,12 +93,20 @@ nrm2[..., K:] = 0
 refw2 = torch.einsum("mrk,mck->rc", xB.double(), nrm2)
 scw2 = torch.einsum("mrk,mck->rc", xB.double().abs(), nrm2.abs()).clamp_min(1e-30)
 report("wgrad dW2 pro", lambda: ops.pw_wgrad(xB, xH, B, H, K, pro=(g, b, a, ms)), refw2, scw2)
-for tile in (1, 2, 3, 0):
+from conv_tasnet_amd.ops import _p, _b3_pieces  # noqa: E402
+outH = torch.empty(M, H, Kp, device=dev)
+outB = torch.empty(M, B, Kp, device=dev)
+for tile in (1, 2, 0):      # 128x64, 256x64, 128x128: the kernels on pre-split weights (the composite's forms), GEMM alone
     ctn.lib.call("ctn_tune", b"b3_tile", tile)
     ops._ws_cache.clear()
     arith(1)
-    print("b3_tile=%d  K1 %6.1f  K3 %6.1f  B1 %6.1f  B5 %6.1f us" % (
-        tile, timeit(lambda: ops.pw_gemm(w1t, xB, H, B, K, trans_w=True, epi_alpha=a)),
-        timeit(lambda: ops.pw_gemm(w2t, xH, B, H, K, trans_w=True, pro=(st2, g, b, a), residual=xB)),
-        timeit(lambda: ops.pw_dgrad_gln(w2, xB, H, B, K, xH, g, a, ms)),
-        timeit(lambda: ops.pw_gemm(w1, xH, B, H, K, trans_w=True, residual=xB))), flush=True)
+    p1, p2 = _b3_pieces(w1, H, B, False), _b3_pieces(w2, B, H, False)          # forward operands
+    q2, q1 = _b3_pieces(w2, H, B, True), _b3_pieces(w1, B, H, True)            # input-gradient operands
+    part = torch.empty((M, ctn.lib.ctn_pw_stats_parts(M, H, Kp), 2), dtype=torch.float64, device=dev)
+    sm = ops._stream()
+    k1 = lambda: ctn.lib.call("ctn_pw_gemm", _p(p1), _p(xB), _p(outH), M, H, B, K, Kp, 2, None, 0, None, None, None, None, None, _p(a), _p(part), 0, sm)
+    k3 = lambda: ctn.lib.call("ctn_pw_gemm", _p(p2), _p(xH), _p(outB), M, B, H, K, Kp, 2, _p(st2), 1, _p(g), _p(b), _p(a), None, _p(xB), None, None, 0, sm)
+    b1 = lambda: ctn.lib.call("ctn_pw_dgrad_gln_planes", _p(q2), _p(xB), _p(outH), M, H, B, K, Kp, _p(xH), _p(g), _p(a), _p(ms), _p(part), sm)
+    b5 = lambda: ctn.lib.call("ctn_pw_gemm", _p(q1), _p(xH), _p(outB), M, B, H, K, Kp, 2, None, 0, None, None, None, None, _p(xB), None, None, 0, sm)
+    print("b3_tile=%d (pre-split weights)  K1 %6.1f  K3 %6.1f  B1 %6.1f  B5 %6.1f us" % (tile, timeit(k1), timeit(k3), timeit(b1), timeit(b5)), flush=True)
+ctn.lib.call("ctn_tune", b"b3_tile", 1)

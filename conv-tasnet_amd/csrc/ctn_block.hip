@@ -23,6 +23,47 @@ enum { P_W1 = 0, P_A1, P_G1, P_B1, P_D, P_A2, P_G2, P_B2, P_W2, NPARAM };
 
 inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
+// One slot of the per-block weight region: an fp32 [I, O] copy (fp32 arithmetic) or the bf16 piece fragments of the same
+// operand (b3 arithmetic, ctn_split_b3_batch) -- the same bytes when H and B are multiples of 32.
+inline size_t wslot_bytes(int B, int H) {
+    size_t n = (size_t)H * B * sizeof(float);
+    const size_t a = ctn_split_b3_bytes(H, B), b = ctn_split_b3_bytes(B, H);
+    if (a > n) n = a;
+    if (b > n) n = b;
+    return align256(n);
+}
+inline bool pieces(int R) { return ctn_gemm_arith() == 1 && R >= 64; }      // the rule of ctn_pw_gemm(trans_w = 2)
+
+// Weight operands of every block, prepared once per call into region [nblocks][2 slots]: slot 0 for the GEMM with H output
+// rows, slot 1 for the one with B output rows.  fwd: (w1 -> H rows, w2 -> B rows) as stored; bwd: (w2 -> H rows, w1 -> B rows)
+// transposed.  tw_h / tw_b receive the trans_w code of ctn_pw_gemm for the prepared operand (2 pieces, 1 fp32 [I, O] copy;
+// backward without pieces uses the stored matrices: no copy, code 1).
+int prepare_weights(const void* const* params, int nblocks, int B, int H, bool backward, char* region, size_t slot,
+                    int* tw_h, int* tw_b, void* stream) {
+    std::vector<const void*> src(nblocks);
+    std::vector<void*> dst(nblocks);
+    int rc;
+    for (int half = 0; half < 2; ++half) {              // 0: the H-row GEMM, 1: the B-row GEMM
+        const int R = half == 0 ? H : B, Cn = half == 0 ? B : H;
+        const int pidx = (half == 0) != backward ? P_W1 : P_W2;      // fwd: H rows <- w1, B rows <- w2; bwd: H rows <- w2, B rows <- w1
+        for (int i = 0; i < nblocks; ++i) {
+            src[i] = ((const void* const*)(params + (size_t)i * NPARAM))[pidx];
+            dst[i] = region + ((size_t)2 * i + half) * slot;
+        }
+        int* const tw = half == 0 ? tw_h : tw_b;
+        if (pieces(R)) {
+            if ((rc = ctn_split_b3_batch(src.data(), dst.data(), nblocks, R, Cn, backward ? 1 : 0, stream))) return rc;
+            *tw = 2;
+        } else if (!backward) {
+            if ((rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, R, Cn, stream))) return rc;     // [R, Cn] -> [Cn, R]
+            *tw = 1;
+        } else {
+            *tw = -1;       // use the stored matrix (trans_w = 1)
+        }
+    }
+    return CTN_OK;
+}
+
 struct FwdWs {
     size_t st1, st2, wt, total;
     int np1;
@@ -33,16 +74,16 @@ FwdWs fwd_ws(int M, int B, int H, int Kp, int nblocks) {
     w.st1 = 0;
     w.st2 = align256((size_t)M * w.np1 * 2 * sizeof(double));
     w.wt = w.st2 + align256((size_t)M * H * 2 * sizeof(double));
-    w.total = w.wt + (size_t)nblocks * 2 * align256((size_t)H * B * sizeof(float));     // [nblocks][w1^T | w2^T]
+    w.total = w.wt + (size_t)nblocks * 2 * wslot_bytes(B, H);                            // [nblocks][w1 operand | w2 operand]
     return w;
 }
 
 struct BwdWs {
-    size_t dn2, s2p, s1p, pc, da1p, slab, total;
+    size_t dn2, s2p, s1p, pc, da1p, slab, wp, total;
     size_t slab_bytes;
     int np2;
 };
-BwdWs bwd_ws(int M, int B, int H, int Kp, int P) {
+BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     BwdWs w;
     w.np2 = ctn_pw_stats_parts(M, H, Kp);
     size_t o = 0;
@@ -54,6 +95,7 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P) {
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
     w.slab_bytes = s1 > s2 ? s1 : s2;
     w.slab = o; o += align256(w.slab_bytes);
+    w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);         // [nblocks][w2 operand (H rows) | w1 operand (B rows)], b3 pieces
     w.total = o;
     return w;
 }
@@ -63,7 +105,7 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P) {
 extern "C" {
 
 size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) { return fwd_ws(M, B, H, Kp, nblocks).total; }
-size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P) { return bwd_ws(M, B, H, Kp, P).total; }
+size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks) { return bwd_ws(M, B, H, Kp, P, nblocks).total; }
 
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* ds, float* ms, int save,
@@ -79,45 +121,39 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     double* const st1 = (double*)((char*)workspace + w.st1);
     double* const st2 = (double*)((char*)workspace + w.st2);
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
-    // [I, O] copies of both 1x1 weights of every block (the fast operand form of the persistent GEMM), one launch each
-    float* const wt = (float*)((char*)workspace + w.wt);
-    const size_t wsz = align256((size_t)H * B * sizeof(float)) / sizeof(float);
-    const bool use_wt = g_ctn_block_wt != 0;        // [I, O] weight copies: 16-byte LDS row writes instead of the transposing scatter
+    // the weight operand of both 1x1 convolutions of every block, prepared once: bf16 piece fragments (b3 arithmetic) or
+    // [I, O] fp32 copies (16-byte LDS row writes instead of the transposing scatter); two launches for the whole stack
+    char* const wreg = (char*)workspace + w.wt;
+    const size_t slot = wslot_bytes(B, H);
+    const bool use_wt = g_ctn_block_wt != 0;
+    int tw1 = 0, tw2 = 0;
+    for (int i = 0; i < nblocks; ++i) {
+        const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
+        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
+    }
     if (use_wt) {
-        std::vector<const void*> src(nblocks);
-        std::vector<void*> dst(nblocks);
-        for (int i = 0; i < nblocks; ++i) {
-            const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
-            for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
-            src[i] = p[P_W1]; dst[i] = wt + (size_t)(2 * i) * wsz;
-        }
-        int rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, H, B, stream);          // w1 [H,B] -> [B,H]
-        if (rc) return rc;
-        for (int i = 0; i < nblocks; ++i) {
-            src[i] = ((const float* const*)(params + (size_t)i * NPARAM))[P_W2]; dst[i] = wt + (size_t)(2 * i + 1) * wsz;
-        }
-        rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, B, H, stream);              // w2 [B,H] -> [H,B]
+        int rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream);
         if (rc) return rc;
     }
     const float* x = x0;
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
-        const float* const w1t = use_wt ? wt + (size_t)(2 * i) * wsz : p[P_W1];
-        const float* const w2t = use_wt ? wt + (size_t)(2 * i + 1) * wsz : p[P_W2];
+        const float* const w1t = use_wt ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W1];
+        const float* const w2t = use_wt ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W2];
         // save = 0 (inference): one h1 / d slot and two ping-pong x slots; save = 1: a slot per block for the backward pass
         float* const h1 = h1s + (save ? (size_t)i * hsz : 0);
         float* const d = ds + (save ? (size_t)i * hsz : 0);
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const ms1 = ms + ((size_t)(save ? i : 0) * 2 + 0) * M * 2;
         float* const ms2 = ms + ((size_t)(save ? i : 0) * 2 + 1) * M * 2;
-        int rc = ctn_pw_gemm(w1t, x, h1, M, H, B, K, Kp, use_wt ? 1 : 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+        int rc = ctn_pw_gemm(w1t, x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                              p[P_A1], st1, 0, stream);
         if (rc) return rc;
         rc = ctn_dw_fwd(h1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, st1, w.np1, p[P_G1], p[P_B1], p[P_A1], ms1,
                         p[P_A2], st2, stream);
         if (rc) return rc;
-        rc = ctn_pw_gemm(w2t, d, out, M, B, H, K, Kp, use_wt ? 1 : 0, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
+        rc = ctn_pw_gemm(w2t, d, out, M, B, H, K, Kp, tw2, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
                          stream);
         if (rc) return rc;
         x = out;
@@ -133,7 +169,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && dout && dxs && dn1s && workspace,
                 "ctn_tcn_gln_bwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_bwd: bad sizes");
-    const BwdWs w = bwd_ws(M, B, H, Kp, P);
+    const BwdWs w = bwd_ws(M, B, H, Kp, P, nblocks);
     if (workspace_bytes < w.total) {
         ctn_set_error("ctn_tcn_gln_bwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
         return CTN_ERR_WORKSPACE;
@@ -148,10 +184,17 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
     void* const wst = side_stream ? side_stream : stream;       // where the weight gradients go
     int rc;
+    for (int i = 0; i < nblocks; ++i)
+        for (int j = 0; j < NPARAM; ++j)
+            CTN_REQUIRE(params[(size_t)i * NPARAM + j] && grads[(size_t)i * NPARAM + j], "ctn_tcn_gln_bwd: block %d parameter / gradient %d is null", i, j);
+    // b3 arithmetic: the transposed weight operands of both input-gradient GEMMs as bf16 pieces, two launches for the stack
+    char* const wreg = ws + w.wp;
+    const size_t slot = wslot_bytes(B, H);
+    int twh = -1, twb = -1;
+    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, stream))) return rc;
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
-        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j] && g[j], "ctn_tcn_gln_bwd: block %d parameter / gradient %d is null", i, j);
         const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
         const float* const h1 = h1s + (size_t)i * hsz;
         const float* const d = ds + (size_t)i * hsz;
@@ -161,7 +204,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         float* const dx = dxs + (size_t)i * xsz;
         float* const dn1 = dn1s + (size_t)i * hsz;      // a slot per block: the side stream still reads it while the chain moves on
         // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
-        rc = ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
+        if (twh == 2) rc = ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
+        else rc = ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
         if (rc) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         rc = ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst);
@@ -180,8 +224,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
             if (rc) return rc;
         }
-        rc = ctn_pw_gemm(p[P_W1], dn1, dx, M, B, H, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr,
-                         nullptr, 0, stream);
+        rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                         nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream);
         if (rc) return rc;
         if (!side_stream) {
             rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
@@ -197,9 +241,9 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
 // ---- cLN stack (causal BASELINE config): the same host-side composite over the un-fused norm kernels ------------------
 namespace {
 struct ClnBwdWs {
-    size_t dn2, dd, dn1, pcw, pcn, dap, slab, total, slab_bytes;
+    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, total, slab_bytes;
 };
-ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P) {
+ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     ClnBwdWs w;
     size_t o = 0;
     const size_t hsz = align256((size_t)M * H * Kp * sizeof(float));
@@ -212,6 +256,7 @@ ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P) {
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
     w.slab_bytes = s1 > s2 ? s1 : s2;
     w.slab = o; o += align256(w.slab_bytes);
+    w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);
     w.total = o;
     return w;
 }
@@ -221,9 +266,9 @@ extern "C" {
 
 size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) {
     (void)M; (void)Kp;
-    return (size_t)nblocks * 2 * align256((size_t)H * B * sizeof(float));      // [nblocks][w1^T | w2^T]
+    return (size_t)nblocks * 2 * wslot_bytes(B, H);      // [nblocks][w1 operand | w2 operand]
 }
-size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P) { return cln_bwd_ws(M, B, H, Kp, P).total; }
+size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks) { return cln_bwd_ws(M, B, H, Kp, P, nblocks).total; }
 
 int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
@@ -236,23 +281,12 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
         return CTN_ERR_WORKSPACE;
     }
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
-    float* const wt = (float*)workspace;
-    const size_t wsz = align256((size_t)H * B * sizeof(float)) / sizeof(float);
-    int rc;
-    {
-        std::vector<const void*> src(nblocks);
-        std::vector<void*> dst(nblocks);
-        for (int i = 0; i < nblocks; ++i) {
-            const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
-            for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
-            src[i] = p[P_W1]; dst[i] = wt + (size_t)(2 * i) * wsz;
-        }
-        if ((rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, H, B, stream))) return rc;
-        for (int i = 0; i < nblocks; ++i) {
-            src[i] = ((const float* const*)(params + (size_t)i * NPARAM))[P_W2]; dst[i] = wt + (size_t)(2 * i + 1) * wsz;
-        }
-        if ((rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, B, H, stream))) return rc;
-    }
+    char* const wreg = (char*)workspace;
+    const size_t slot = wslot_bytes(B, H);
+    int rc, tw1 = 0, tw2 = 0;
+    for (int i = 0; i < nblocks; ++i)
+        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(params[(size_t)i * NPARAM + j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
+    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream))) return rc;
     const float* x = x0;
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
@@ -260,14 +294,14 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
         float* const h1 = h1s + s * hsz; float* const n1 = n1s + s * hsz; float* const d = ds + s * hsz; float* const n2 = n2s + s * hsz;
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const stb = st + s * 4 * ssz;
-        if ((rc = ctn_pw_gemm(wt + (size_t)(2 * i) * wsz, x, h1, M, H, B, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                              nullptr, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i) * slot), x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, 0, stream))) return rc;
         if ((rc = ctn_cln_fwd(h1, n1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], stream))) return rc;
         if ((rc = ctn_dw_fwd(n1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, stream))) return rc;
         if ((rc = ctn_cln_fwd(d, n2, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], stream))) return rc;
-        if ((rc = ctn_pw_gemm(wt + (size_t)(2 * i + 1) * wsz, n2, out, M, B, H, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr,
-                              nullptr, x, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i + 1) * slot), n2, out, M, B, H, K, Kp, tw2, nullptr, 0, nullptr, nullptr,
+                              nullptr, nullptr, x, nullptr, nullptr, 0, stream))) return rc;
         x = out;
     }
     return CTN_OK;
@@ -281,7 +315,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && dout && dxs && dh1s && workspace,
                 "ctn_tcn_cln_bwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_bwd: bad sizes");
-    const ClnBwdWs w = cln_bwd_ws(M, B, H, Kp, P);
+    const ClnBwdWs w = cln_bwd_ws(M, B, H, Kp, P, nblocks);
     if (workspace_bytes < w.total) {
         ctn_set_error("ctn_tcn_cln_bwd: workspace too small (%zu < %zu)", workspace_bytes, w.total);
         return CTN_ERR_WORKSPACE;
@@ -297,10 +331,16 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
     void* const wst = side_stream ? side_stream : stream;
     int rc;
+    for (int i = 0; i < nblocks; ++i)
+        for (int j = 0; j < NPARAM; ++j)
+            CTN_REQUIRE(params[(size_t)i * NPARAM + j] && grads[(size_t)i * NPARAM + j], "ctn_tcn_cln_bwd: block %d parameter / gradient %d is null", i, j);
+    char* const wreg = ws + w.wp;
+    const size_t slot = wslot_bytes(B, H);
+    int twh = -1, twb = -1;
+    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, stream))) return rc;
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
-        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j] && g[j], "ctn_tcn_cln_bwd: block %d parameter / gradient %d is null", i, j);
         const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
         const float* const h1 = h1s + (size_t)i * hsz; const float* const n1 = n1s + (size_t)i * hsz;
         const float* const d = ds + (size_t)i * hsz; const float* const n2 = n2s + (size_t)i * hsz;
@@ -308,8 +348,8 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;
         float* const dx = dxs + (size_t)i * xsz;
         float* const dh1 = dh1s + (size_t)i * hsz;          // a slot per block: the side stream reads it while the chain moves on
-        if ((rc = ctn_pw_gemm(p[P_W2], dy, dn2, M, H, B, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                              nullptr, 0, stream))) return rc;
+        if ((rc = ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         if ((rc = ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
         if ((rc = ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap, pcn, stream))) return rc;
@@ -321,8 +361,8 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if ((rc = ctn_cln_bwd_finalize(pcn, dap, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], stream))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         if (side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
-        if ((rc = ctn_pw_gemm(p[P_W1], dh1, dx, M, B, H, K, Kp, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr,
-                              nullptr, 0, stream))) return rc;
+        if ((rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream))) return rc;
         if (!side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
     }
     if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;

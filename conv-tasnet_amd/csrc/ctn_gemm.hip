@@ -1045,6 +1045,7 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
     a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
+    CTN_REQUIRE(trans_w != 2 || b3_fwd(R), "ctn_pw_gemm: trans_w = 2 (pre-split weight pieces) needs the b3 arithmetic and R >= 64");
     if (b3_fwd(R)) {
         ctn_b3_launch_fwd(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
                           (hipStream_t)stream);
@@ -1062,26 +1063,51 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
 
 // dN[m] = W^T . dOut[m]  (W stored [Cn=O_fwd, R=I_fwd]) plus the two per-utterance sums that
 // gLN backward needs:  S1 = sum gamma*dN, S2 = sum gamma*dN*xhat, xhat = (prelu(y)-mean)*rstd.
-int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
-                     const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
-                     void* stream) {
-    int rc = check_common("ctn_pw_dgrad_gln", W, dOut, dN, M, R, Cn, K, Kp);
+static int dgrad_gln(const char* fn, const float* W, int planes, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                     const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part, void* stream) {
+    int rc = check_common(fn, W, dOut, dN, M, R, Cn, K, Kp);
     if (rc) return rc;
-    CTN_REQUIRE(y && gamma && alpha && ms && sums_part, "ctn_pw_dgrad_gln: null pointer");
-    CTN_REQUIRE(aligned16(y), "ctn_pw_dgrad_gln: y must be 16-byte aligned");
+    CTN_REQUIRE(y && gamma && alpha && ms && sums_part, "%s: null pointer", fn);
+    CTN_REQUIRE(aligned16(y), "%s: y must be 16-byte aligned", fn);
+    CTN_REQUIRE(!planes || b3_fwd(R), "%s: pre-split weight pieces need the b3 arithmetic and R >= 64", fn);
     PwArgs a{};
     a.store_f32 = 1;
     a.W = W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
     if (b3_fwd(R)) {
-        ctn_b3_launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
+        ctn_b3_launch_fwd(a, planes ? 2 : 1, false, false, false, false, true, (hipStream_t)stream);
     } else if (use_pk()) {
         rc = launch_pk(a, 1, false, false, false, false, true, (hipStream_t)stream);
         if (rc) return rc;
     } else {
         launch_fwd(a, 1, false, false, false, false, true, (hipStream_t)stream);
     }
-    CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln");
+    CTN_CHECK_LAUNCH(fn);
+    return CTN_OK;
+}
+
+int ctn_pw_dgrad_gln(const float* W, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                     const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                     void* stream) {
+    return dgrad_gln("ctn_pw_dgrad_gln", W, 0, dOut, dN, M, R, Cn, K, Kp, y, gamma, alpha, ms, sums_part, stream);
+}
+
+// the same on pre-split weight pieces (ctn_split_b3_batch with k_major = 1 on the stored [Cn, R] matrix)
+int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                            const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                            void* stream) {
+    return dgrad_gln("ctn_pw_dgrad_gln_planes", (const float*)Wp, 1, dOut, dN, M, R, Cn, K, Kp, y, gamma, alpha, ms, sums_part, stream);
+}
+
+size_t ctn_split_b3_bytes(int R, int Cn) { return ctn_b3_planes_bytes(R, Cn); }
+
+// dst[i] = bf16 piece fragments of the GEMM weight operand A [R, Cn] taken from src[i]: k_major = 0: src is stored [R, Cn];
+// k_major = 1: src is stored [Cn, R] (its transpose is the operand).  HOST arrays of device pointers; see include/ctn_hip.h.
+int ctn_split_b3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream) {
+    CTN_REQUIRE(src && dst && n > 0 && R > 0 && Cn > 0, "ctn_split_b3_batch: bad arguments");
+    for (int i = 0; i < n; ++i) CTN_REQUIRE(src[i] && dst[i] && aligned16(dst[i]), "ctn_split_b3_batch: matrix %d: null or unaligned pointer", i);
+    ctn_b3_launch_split(src, dst, n, R, Cn, k_major, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_split_b3_batch");
     return CTN_OK;
 }
 
@@ -1131,7 +1157,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_mf") && (value == 16 || value == 32)) g_w4_mf = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
     else if (!strcmp(key, "arith") && (value == 0 || value == 1)) g_arith = value;
-    else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 3) g_ctn_b3_tile = value;
+    else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 2) g_ctn_b3_tile = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;

@@ -328,6 +328,212 @@ __global__ __launch_bounds__(NT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward / input-gradient GEMM on PRE-SPLIT weights ("planes"): the product kernel of the composite stacks.
+//
+// The weights change once per step, the activations once per launch: ctn_split_b3_batch splits every 1x1 weight once
+// into bf16 piece fragments stored in MFMA operand order, and this kernel reads them straight into registers --
+//   block (rt, kt, p) = 1 KiB = the A operand of v_mfma_f32_32x32x16_bf16 for rows 32 rt .. + 31, contraction steps
+//   16 kt .. + 15, piece p (0 = hi, 1 = lo): lane l holds row 32 rt + l % 32, steps 16 kt + 8 (l / 32) .. + 7 (16 bytes);
+//   blocks ordered [rt][kt][p], so the four blocks of one 32-deep k-tile are 4 KiB contiguous (one per-lane address, four
+//   immediate offsets) and a wave instruction reads 1 KiB contiguous.
+// No LDS traffic, no conversion work and no sharing for the weight operand: the four waves of a workgroup own disjoint
+// row ranges (4 x 1 wave grid, each wave WM rows x all TN columns).  Only the activation tile goes through LDS: loaded
+// once per workgroup, PReLU+gLN prologue, split into two pieces, stored channel-major, read by every wave with the
+// transposing ds_read_b64_tr_b16.  Two LDS stages -> one barrier per k-tile; weight fragments and the next activation
+// tile are prefetched one k-tile ahead in registers (two k-tiles ahead measured slower: 35 vs 30 us, the extra register
+// sets cost a resident workgroup).  Per wave and k-tile (128 x 64 tile): 4 + 2 global 16-byte loads, ~30 VALU (split of
+// 8 values), 4 ds_write_b64, 16 ds_read_b64_tr_b16, 12 MFMAs.
+// The MFMA order per accumulator is that of pw_gemm_b3_kernel (lo.hi, hi.lo, hi.hi per 16-deep step): same values.
+// ---------------------------------------------------------------------------------------------------------
+template <typename TL>
+struct B3P {
+    static constexpr int PB = TL::TN + 32;
+    static constexpr int STAGE_ELEMS = 2 * XK * PB;                            // both pieces of one k-tile
+    static constexpr int MAIN_BYTES = 2 * STAGE_ELEMS * 2;                     // two stages
+    static constexpr int EPI_BYTES = TL::STAGE_FLOATS * 4;
+    static constexpr int SMEM_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
+
+__device__ __forceinline__ bf16x8 buf_ld_frag(__amdgpu_buffer_rsrc_t r, int voff, int imm) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0));
+}
+
+template <typename TL, int PRO, int EPI>
+__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? 4 : 2)
+void pw_gemm_b3p_kernel(PwArgs a) {
+    constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, NTH = TL::NTH;
+    static_assert(TL::WGN == 1, "each wave owns its rows: 4 x 1 wave grid");
+    using L = B3P<TL>;
+    constexpr int PB = L::PB;
+    constexpr int B_L = XK * TN / 4 / NTH;                                     // float4 loads per thread per k-tile
+    static_assert(B_L >= 1, "tile too narrow for the workgroup");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[L::SMEM_BYTES];
+    __shared__ double red[NTH / 64];
+    __bf16* const Bp = reinterpret_cast<__bf16*>(smem_raw);                    // [stage][piece][XK][PB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int rt = bid % a.tiles_r; bid /= a.tiles_r;
+    const int ct = bid % a.tiles_c;
+    const int m = bid / a.tiles_c;
+    const int r0 = rt * TM, c0 = ct * TN;
+    const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
+
+    float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        finalize_stats<NTH>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts, (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
+        p_alpha = a.pro_alpha[0];
+        if (a.pro_ms_out != nullptr && rt == 0 && ct == 0 && tid == 0) {
+            a.pro_ms_out[2 * m] = p_mean;
+            a.pro_ms_out[2 * m + 1] = p_rstd;
+        }
+    }
+    const int nk = (a.Cn + XK - 1) / XK, Cnp = nk * XK;
+    const int Rp = (a.R + 31) / 32 * 32;
+    // weight fragments: rows past Rp fall off the end of the planes and read 0 (rows R .. Rp-1 are stored as zeros)
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)Rp * (unsigned)Cnp * 4u);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
+    __amdgpu_buffer_rsrc_t rsG = rsX, rsBt = rsX;
+    if constexpr (PRO == PRO_PRELU_NORM) {
+        rsG = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
+        rsBt = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
+    }
+    int voA[MT], voB[B_L], voP[B_L];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) voA[i] = ((r0 + wm * WM) / 32 + i) * (Cnp / 16) * 2048 + lane * 16;      // 2 KiB per (rt, kt)
+#pragma unroll
+    for (int j = 0; j < B_L; ++j) {
+        const int i = tid / (TN / 4) + (4 * NTH / TN) * j;
+        voB[j] = (i * a.Kp + c0 + (tid % (TN / 4)) * 4) * 4;
+        voP[j] = i * 4;
+    }
+    const int sB = XK * a.Kp * 4;
+
+    auto load_a = [&](int kt, bf16x8 (&fa)[MT][2][2]) {          // [row tile][k step][piece]
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) fa[i][ks][p] = buf_ld_frag(rsW, voA[i] + kt * 4096, (ks * 2 + p) * 1024);
+    };
+    auto load_b = [&](int kt, float4 (&rb)[B_L], float2 (&rp)[B_L]) {
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            rb[j] = buf_ld4(rsX, voB[j] + kt * sB, 0);
+            if constexpr (PRO == PRO_PRELU_NORM)
+                rp[j] = make_float2(buf_ld1(rsG, voP[j] + kt * XK * 4, 0), buf_ld1(rsBt, voP[j] + kt * XK * 4, 0));
+            else
+                rp[j] = make_float2(0.f, 0.f);
+        }
+    };
+    auto store_b = [&](int stage, const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
+        __bf16* const S = Bp + stage * L::STAGE_ELEMS;
+#pragma unroll
+        for (int j = 0; j < B_L; ++j) {
+            const int i = tid / (TN / 4) + (4 * NTH / TN) * j, k = (tid % (TN / 4)) * 4;
+            float4 v = rb[j];
+            if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
+            bf16x4 hi, lo;
+            split2x4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(S + i * PB + k) = hi;
+            *reinterpret_cast<bf16x4*>(S + (XK + i) * PB + k) = lo;
+        }
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int stage, const bf16x8 (&fa)[MT][2][2]) {
+        const __bf16* const S = Bp + stage * L::STAGE_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[NTL][2];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bfr[j][p] = frag_tr(S + (p * XK + ks * 16) * PB + j * 32, PB, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][1], bfr[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][0], bfr[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][0], bfr[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // k-tile kt: weight fragments in one register set, activation tile in LDS stage kt & 1; while it is multiplied, tile
+    // kt + 1 (already in registers) is split into the other stage and the loads of tile kt + 2 are issued.
+    bf16x8 fa0[MT][2][2], fa1[MT][2][2];
+    float4 rb[B_L];
+    float2 rp[B_L];
+    load_a(0, fa0);
+    load_b(0, rb, rp);
+    store_b(0, rb, rp);
+    if (nk > 1) { load_a(1, fa1); load_b(1, rb, rp); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute(0, fa0);
+        if (kt + 1 < nk) store_b(1, rb, rp);
+        __syncthreads();
+        if (kt + 2 < nk) { load_a(kt + 2, fa0); load_b(kt + 2, rb, rp); }
+        if (kt + 1 < nk) {
+            compute(1, fa1);
+            if (kt + 2 < nk) store_b(0, rb, rp);
+            __syncthreads();
+            if (kt + 3 < nk) { load_a(kt + 3, fa1); load_b(kt + 3, rb, rp); }
+        }
+    }
+    gemm_epilogue<TL, EPI>(a, acc, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+}
+
+// W fp32 -> fragment-ordered bf16 pieces (layout above).  value(r, k) = W[r * sr + k * sk]: (sr, sk) = (Cn, 1) for a stored
+// [R, Cn] matrix, (1, R) for a stored [Cn, R] matrix used transposed.  One thread per (rt, kt, lane); zero fill to Rp x Cnp.
+constexpr int SPLIT_MAX = 64;
+struct SplitArgs {
+    const float* src[SPLIT_MAX];
+    __bf16* dst[SPLIT_MAX];
+    int R, Cn, sr, sk, nkt;        // nkt = Cnp / 16
+};
+__global__ __launch_bounds__(256) void split_b3_kernel(SplitArgs a) {
+    const float* __restrict__ W = a.src[blockIdx.z];
+    __bf16* __restrict__ D = a.dst[blockIdx.z];
+    const int lane = threadIdx.x & 63;
+    const int kt = blockIdx.x * 4 + (threadIdx.x >> 6), rt = blockIdx.y;
+    if (kt >= a.nkt) return;
+    const int r = rt * 32 + (lane & 31), k0 = kt * 16 + (lane >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (r < a.R && k0 + e < a.Cn) ? W[(size_t)r * a.sr + (size_t)(k0 + e) * a.sk] : 0.f;
+    bf16x4 h0, l0, h1, l1;
+    split2x4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+    split2x4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+    __bf16* const blk = D + ((size_t)(rt * a.nkt + kt) * 2) * 512 + lane * 8;      // 512 bf16 = 1 KiB per block
+    *reinterpret_cast<bf16x8*>(blk) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<bf16x8*>(blk + 512) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <typename TL>
+void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+}
+
 template <typename TL>
 void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
@@ -350,11 +556,11 @@ void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool 
 }  // namespace
 
 // ---- host side, used by the entry points of ctn_gemm.hip ---------------------------------------------------------
-static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64   (ctn_tune("b3_tile", id)); in-step A/B: 12.0 / 11.5 / - / 12.0 ms
+static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step 11.56 / 11.20 / 11.50 ms
 static int g_ctn_b3_wgrad_blocks = 512;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
 static void ctn_b3_tile_dims(int* tm, int* tn) {
-    static const int d[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
     *tm = d[g_ctn_b3_tile][0];
     *tn = d[g_ctn_b3_tile][1];
 }
@@ -364,11 +570,37 @@ static void ctn_b3_launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, b
     ctn_b3_tile_dims(&tm, &tn);
     a.tiles_r = ctn_cdiv(a.R, tm);
     a.tiles_c = ctn_cdiv(a.Kp, tn);
+    if (trans_w == 2) {             // a.W = fragment-ordered pieces (ctn_split_b3_batch)
+        switch (g_ctn_b3_tile) {
+            case 1: launch_b3p_tile<Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            case 2: launch_b3p_tile<Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            default: launch_b3p_tile<Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+        }
+        return;
+    }
     switch (g_ctn_b3_tile) {
         case 1: launch_b3_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 2: launch_b3_tile<T64x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 3: launch_b3_tile<T64x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 2: launch_b3_tile<Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         default: launch_b3_tile<T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+    }
+}
+
+static size_t ctn_b3_planes_bytes(int R, int Cn) {
+    return (size_t)((R + 31) / 32 * 32) * (size_t)((Cn + XK - 1) / XK * XK) * 4;
+}
+
+static void ctn_b3_launch_split(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, hipStream_t st) {
+    for (int o = 0; o < n; o += SPLIT_MAX) {
+        SplitArgs sa{};
+        const int cnt = n - o < SPLIT_MAX ? n - o : SPLIT_MAX;
+        for (int i = 0; i < cnt; ++i) {
+            sa.src[i] = (const float*)src[o + i];
+            sa.dst[i] = (__bf16*)dst[o + i];
+        }
+        sa.R = R; sa.Cn = Cn;
+        sa.sr = k_major ? 1 : Cn; sa.sk = k_major ? R : 1;
+        sa.nkt = (Cn + XK - 1) / XK * 2;
+        hipLaunchKernelGGL(split_b3_kernel, dim3(ctn_cdiv(sa.nkt, 4), (R + 31) / 32, cnt), dim3(256), 0, st, sa);
     }
 }
 

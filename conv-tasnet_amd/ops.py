@@ -167,10 +167,26 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
                  _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
                  int(relu_out), _stream())
         return out, epi_part
-    lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, int(trans_w),
+    tw = int(trans_w)
+    if _b3_planes_ok(R) and not relu_out:
+        W, tw = _b3_pieces(W, R, Cn, bool(trans_w)), 2           # the product kernel of the b3 arithmetic (pre-split weights)
+    lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, tw,
              _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
              int(relu_out), _stream())
     return out, epi_part
+
+
+def _b3_planes_ok(R):
+    return R >= 64 and lib.ctn_gemm_arith() == 1
+
+
+def _b3_pieces(W, R, Cn, k_major):
+    """bf16 piece fragments of one GEMM weight operand [R, Cn] (ctn_split_b3_batch); W stored [Cn, R] when k_major."""
+    dst = torch.empty(lib.ctn_split_b3_bytes(R, Cn), dtype=torch.uint8, device=W.device)
+    src_t = (ctypes.c_void_p * 1)(W.data_ptr())
+    dst_t = (ctypes.c_void_p * 1)(dst.data_ptr())
+    lib.call("ctn_split_b3_batch", src_t, dst_t, 1, R, Cn, int(k_major), _stream())
+    return dst
 
 
 def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
@@ -183,6 +199,9 @@ def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
         planes = _split_planes(W, Cn, R, True)
         lib.call("ctn_pw_dgrad_gln_x6", _p(planes), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha),
                  _p(ms), _p(part), _stream())
+    elif _b3_planes_ok(R):
+        lib.call("ctn_pw_dgrad_gln_planes", _p(_b3_pieces(W, R, Cn, True)), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma),
+                 _p(alpha), _p(ms), _p(part), _stream())
     else:
         lib.call("ctn_pw_dgrad_gln", _p(W), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha), _p(ms),
                  _p(part), _stream())
@@ -569,7 +588,7 @@ class TcnGln(torch.autograd.Function):
                 o += n
         dxs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
         dn1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
-        nbytes = lib.ctn_tcn_gln_bwd_workspace(M, B, H, Kp, P)
+        nbytes = lib.ctn_tcn_gln_bwd_workspace(M, B, H, Kp, P, nb)
         ws = _workspace(nbytes, dev, "tcn_bwd")
         side = _side_stream(dev) if (direct and _SIDE_ENABLED) else None
         lib.call("ctn_tcn_gln_bwd", _ptr_table(params), _ptr_table(gdst), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms),
@@ -653,7 +672,7 @@ class TcnCln(torch.autograd.Function):
                 o += n
         dxs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
         dh1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
-        nbytes = lib.ctn_tcn_cln_bwd_workspace(M, B, H, Kp, P)
+        nbytes = lib.ctn_tcn_cln_bwd_workspace(M, B, H, Kp, P, nb)
         ws = _workspace(nbytes, dev, "tcn_cln_bwd")
         side = _side_stream(dev) if (direct and _SIDE_ENABLED and _CLN_SIDE) else None
         lib.call("ctn_tcn_cln_bwd", _ptr_table(params), _ptr_table(gdst), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]),

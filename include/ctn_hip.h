@@ -46,7 +46,8 @@ int ctn_stream_order(void* from, void* to);
 
 /* Out[m] = op(W) . f(X[m])  (+ residual[m]),   X:[M,Cn,Kp]  Out:[M,R,Kp]
  *   trans_w = 0: W is [R,Cn] (forward);  trans_w = 1: W is [Cn,R] (input gradient, or forward on a transposed copy:
- *     the fast form -- ctn_transpose_batch).
+ *     the fast form of the fp32 arithmetic -- ctn_transpose_batch);  trans_w = 2: W is a block of pre-split bf16 pieces
+ *     from ctn_split_b3_batch (b3 arithmetic, R >= 64: the fast form there).
  *   pro_part != NULL: f(x)[i,k] = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i]
  *     for k < K, 0 otherwise; (mean_m, rstd_m) are finalised from the [M, pro_nparts, 2] fp64
  *     (sum, sum of squares) partials of prelu(x) -- global LayerNorm, src/conv_tasnet.py:358-360 --
@@ -97,6 +98,17 @@ int ctn_tune(const char* key, int value);
  * Selected by CTN_GEMM_ARITH=b3|fp32 at first use or ctn_tune("arith", 0|1) between steps; layers with fewer than 64
  * output rows always use the fp32 kernels. */
 int ctn_gemm_arith(void);
+/* b3 arithmetic only: the weight operand pre-split once per step.  dst[i] receives the two bf16 pieces of the GEMM operand
+ * A [R, Cn] (rows = output channels of THAT GEMM, Cn = its contraction) in MFMA fragment order, zero-filled to multiples
+ * of 32: ctn_split_b3_bytes(R, Cn) bytes each, 16-byte aligned.  k_major = 0: src[i] is stored [R, Cn] (forward layers);
+ * k_major = 1: src[i] is stored [Cn, R] and used transposed (input gradients of the same layers).  HOST arrays of device
+ * pointers, any n.  ctn_pw_gemm(trans_w = 2) and ctn_pw_dgrad_gln_planes take such a block as W: no conversion work and
+ * no LDS traffic for the weights inside the GEMM; results are bitwise those of the fp32-weight forms under b3. */
+size_t ctn_split_b3_bytes(int R, int Cn);
+int ctn_split_b3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream);
+int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                            const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                            void* stream);
 
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
@@ -176,7 +188,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
                     const float* dout, float* dxs, float* dn1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
-size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P);
+size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks);
 
 /* The same for a stack of cLN TemporalBlocks (norm_type = 'cLN': the causal BASELINE config), un-fused norms: per block
  * forward  1x1 -> cLN(PReLU) -> depthwise -> cLN(PReLU) -> 1x1 + residual,  backward the adjoint chain with the two weight
@@ -193,7 +205,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
                     const float* st, const float* dout, float* dxs, float* dh1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
-size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P);
+size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks);
 
 /* ---- channel-wise LayerNorm, src/conv_tasnet.py:313-335 (per frame, biased variance) -----
  * Out = gamma*((a-mean_k)*rstd_k)+beta with a = prelu(Y,alpha) if alpha != NULL else Y.
