@@ -210,16 +210,25 @@ void pw_gemm_b3_kernel(PwArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient: dW[r,c] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  Both operands have the contraction (frames) contiguous:
-// row-major piece planes, ds_read_b128 fragments.  128 x 128 output tile per 256-thread workgroup (each wave 64 x 64),
-// split over (utterance, frame chunk) into fp32 slabs summed in fixed order by slab_reduce_kernel.
+// row-major piece planes, ds_read_b128 fragments.  128 x 128 output tile per 512-thread workgroup: 8 waves as 2 x 4, each
+// 64 rows x 32 columns -- twice the waves of a 2 x 2 arrangement for the same tile, so the split of the two activation
+// tiles (both operands are activations: ~100 VALU instructions per thread and k-tile at 256 threads) is spread over 8
+// waves and 2-3 resident workgroups give every SIMD 4-6 waves to hide the global-load latency with.  Two LDS stages, one
+// barrier per 32-frame k-tile; the next k-tile's global loads wait in registers.  Split over (utterance, frame chunk) into
+// fp32 slabs summed in fixed order by slab_reduce_kernel.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int WNT = 512;
 template <int PRO>
-__global__ __launch_bounds__(NT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * BM * XPA];
-    __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * BN * XPA];
+__global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
+    constexpr int PLANE = BM * XPA, STAGE = 2 * PLANE;        // bf16 elements: one piece plane, both pieces of one operand
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * STAGE];          // [stage][piece][BM][XPA]
+    __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
+    const int wm = wave >> 2, wn = wave & 3;
+    // XCD-aware order: the output tiles of one (utterance, chunk) split read the same activation rows -- give them
+    // consecutive logical ids, i.e. the same XCD and its L2 (dealt round-robin they land on 8 different L2s and every
+    // operand byte comes from HBM once per tile: 208 MB instead of 79 MB per launch at the paper shapes)
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int rt = bid % a.tiles_r; bid /= a.tiles_r;
     const int ct = bid % a.tiles_c; bid /= a.tiles_c;
     const int sp = bid;
@@ -236,83 +245,100 @@ __global__ __launch_bounds__(NT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
         p_rstd = a.pro_ms[2 * m + 1];
         p_alpha = a.pro_alpha[0];
     }
-    // staging map: 8 threads per row (32 frames = 8 float4), 32 rows per pass, 4 passes for 128 rows.  Rows past R / Cn
-    // fall off the end of the utterance's matrix and read 0; frames past the chunk end are masked by the per-lane offset.
+    // staging map: 8 threads per row (32 frames = 8 float4), 64 rows per pass, 2 passes for 128 rows.  Rows past R / Cn
+    // fall off the end of the utterance's matrix and read 0; frames past the chunk end are pushed out of range.
     const __amdgpu_buffer_rsrc_t rsG = make_rsrc(Gm, (unsigned)a.R * (unsigned)a.Kp * 4u);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
-    float4 ra[4], rb[4];
-    float2 rg[4];
+    constexpr int PF = 3;           // k-tiles of global loads in flight (register ring)
+    float4 ra[PF][2], rb[PF][2];
+    float2 rg[2];
     if constexpr (PRO == PRO_PRELU_NORM) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = c0 + (tid >> 3) + 32 * j;
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + (tid >> 3) + 64 * j;
             rg[j] = c < a.Cn ? make_float2(a.pro_gamma[c], a.pro_beta[c]) : make_float2(0.f, 0.f);
         }
     }
     const int nk = (ke - kb + XK - 1) / XK;
     const int kq = (tid & 7) * 4;
-    auto load_regs = [&](int kt) {
+    auto load_regs = [&](int kt, float4 (&qa)[2], float4 (&qb)[2]) {
         const int k = kb + kt * XK + kq;
-        const unsigned oob = k < ke ? 0u : 0x80000000u;  // past the chunk: push the offset out of range -> reads 0
+        const unsigned oob = k < ke ? 0u : 0x80000000u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = (tid >> 3) + 32 * j;
-            ra[j] = buf_ld4(rsG, (int)((unsigned)(((r0 + row) * a.Kp + k) * 4) + oob), 0);
-            rb[j] = buf_ld4(rsX, (int)((unsigned)(((c0 + row) * a.Kp + k) * 4) + oob), 0);
+        for (int j = 0; j < 2; ++j) {
+            const int row = (tid >> 3) + 64 * j;
+            qa[j] = buf_ld4(rsG, (int)((unsigned)(((r0 + row) * a.Kp + k) * 4) + oob), 0);
+            qb[j] = buf_ld4(rsX, (int)((unsigned)(((c0 + row) * a.Kp + k) * 4) + oob), 0);
         }
     };
     auto write_one = [&](__bf16* P, int row, const float4& v) {
         bf16x4 hi, lo;
         split2x4(v, hi, lo);
         *reinterpret_cast<bf16x4*>(P + row * XPA + kq) = hi;
-        *reinterpret_cast<bf16x4*>(P + (BM + row) * XPA + kq) = lo;
+        *reinterpret_cast<bf16x4*>(P + PLANE + row * XPA + kq) = lo;
     };
-    auto write_lds = [&](int kt) {
+    auto write_lds = [&](int kt, int stage, const float4 (&qa)[2], const float4 (&qb)[2]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = (tid >> 3) + 32 * j;
-            write_one(Ap, row, ra[j]);
-            float4 x = rb[j];
+        for (int j = 0; j < 2; ++j) {
+            const int row = (tid >> 3) + 64 * j;
+            write_one(Ap + stage * STAGE, row, qa[j]);
+            float4 x = qb[j];
             // (frames past the chunk end are frames >= Kp >= K: the prologue zeroes them like every frame >= K)
             if constexpr (PRO == PRO_PRELU_NORM) x = pro_apply(x, kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
-            write_one(Bp, row, x);
+            write_one(Bp + stage * STAGE, row, x);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2];                  // rows wm * 64 + 32 i, columns wn * 32
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     const int l31 = lane & 31, lhi = lane >> 5;
-    if (nk > 0) load_regs(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        write_lds(kt);
-        __syncthreads();
-        if (kt + 1 < nk) load_regs(kt + 1);
+    auto compute = [&](int stage) {
+        const __bf16* const As = Ap + stage * STAGE;
+        const __bf16* const Bs = Bp + stage * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][2], bfr[2][2];
+            bf16x8 af[2][2], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int p = 0; p < 2; ++p) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * BM + wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
-                    bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bp + (p * BN + wn * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
-                }
+                for (int i = 0; i < 2; ++i)
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + (wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
+                bfr[p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + (wn * 32 + l31) * XPA + ks * 16 + lhi * 8);
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
-                }
+            for (int i = 0; i < 2; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[0], acc[i], 0, 0, 0);
+            }
         }
+    };
+    // Register ring of PF k-tiles: at the top of iteration kt, LDS stage kt % 2 holds tile kt, ring slots (kt + 1 .. kt + PF - 1)
+    // % PF hold tiles kt + 1 .. in flight or landed.  One workgroup per CU (256 workgroups, the measured optimum in the step)
+    // has no other workgroup to hide the load latency behind: distance 1 left ~1 us of every 1.4 us k-tile waiting.
+    // Unrolled by 6: ring slot and stage indices are compile-time constants.
+    if (nk > 0) {
+        load_regs(0, ra[0], rb[0]);
+        if (nk > 1) load_regs(1, ra[1], rb[1]);
+        if (nk > 2) load_regs(2, ra[2], rb[2]);
+        write_lds(0, 0, ra[0], rb[0]);
         __syncthreads();
+    }
+    for (int kt0 = 0; kt0 < nk; kt0 += 6) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int kt = kt0 + u;
+            if (kt < nk) {
+                if (kt + PF < nk) load_regs(kt + PF, ra[u % PF], rb[u % PF]);          // slot of tile kt: already in LDS
+                compute(u % 2);
+                if (kt + 1 < nk) write_lds(kt + 1, (u + 1) % 2, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                __syncthreads();
+            }
+        }
     }
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
@@ -320,14 +346,10 @@ __global__ __launch_bounds__(NT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = r0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int c = c0 + wn * 64 + nt * 32 + l31;
-                if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = acc[mt][nt][e];
-            }
+            const int c = c0 + wn * 32 + l31;
+            if (r < a.R && c < a.Cn) S[(size_t)r * a.Cn + c] = acc[mt][e];
         }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Forward / input-gradient GEMM on PRE-SPLIT weights ("planes"): the product kernel of the composite stacks.
@@ -557,7 +579,7 @@ void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool 
 
 // ---- host side, used by the entry points of ctn_gemm.hip ---------------------------------------------------------
 static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step 11.56 / 11.20 / 11.50 ms
-static int g_ctn_b3_wgrad_blocks = 512;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
+static int g_ctn_b3_wgrad_blocks = 256;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
 static void ctn_b3_tile_dims(int* tm, int* tn) {
     static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
@@ -620,7 +642,7 @@ static int ctn_b3_launch_wgrad(WgArgs& a, bool pro, hipStream_t st) {
     a.tiles_r = ctn_cdiv(a.R, BM);
     a.tiles_c = ctn_cdiv(a.Cn, BN);
     const int nsplit = a.M * a.chunks_per_m;
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(NT);
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(WNT);
     if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_PRELU_NORM>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_NONE>), grid, block, 0, st, a);
     return nsplit;
