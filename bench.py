@@ -155,8 +155,11 @@ def _family(name, a):
         if trans_w and residual:
             return "B5 pw_gemm<T,EPI_RESIDUAL> (input gradient W1^T.dh1 + dout)", "mfma", shape
         return "pw_gemm plain (encoder / bottleneck / mask / decoder, fwd or dgrad)", "mfma", shape
-    if name == "ctn_pw_dgrad_gln":
+    if name in ("ctn_pw_dgrad_gln", "ctn_pw_dgrad_gln_planes"):
         return "B1 pw_gemm<T,EPI_GLN_BWD> (input gradient W2^T.dout + gLN backward sums)", "mfma", (a[3], a[4], a[5])
+    if name == "ctn_split_b3_batch":
+        return ("weight split into bf16 pieces, one launch per GEMM -- per-kernel probe path only (the timed composite path "
+                "issues 4 batched launches per step)"), "hbm", None
     if name == "ctn_pw_wgrad":
         if a[11]:
             fam = "B2 pw_wgrad<PRO> + slab_reduce (dW2 = dout . gLN2(prelu(d))^T)"
@@ -177,7 +180,7 @@ def _gemm_bytes(name, a, K):
     t = 4.0 * M * K
     if name == "ctn_pw_gemm":
         return t * (Cn + R + (R if a[15] else 0))                 # X, Out, residual
-    if name == "ctn_pw_dgrad_gln":
+    if name in ("ctn_pw_dgrad_gln", "ctn_pw_dgrad_gln_planes"):
         return t * (Cn + 2 * R)                                   # dOut, dN, y
     return t * (R + Cn)                                           # weight gradient: both activations
 

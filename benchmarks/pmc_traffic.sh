@@ -1,16 +1,16 @@
 # HBM traffic of one kernel from the PMC counters, as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in
 # SEPARATE passes (TCC slots), FETCH_SIZE doubled on gfx950 for wide coalesced reads, WRITE_SIZE exact.
-# usage (GPU box): bash benchmarks/pmc_traffic.sh <kernel-name-substring> <script.py> <out.json> [family label]
+# usage (GPU box): bash benchmarks/pmc_traffic.sh <kernel-name-substring> <script.py> <out.json> [family label] [script args] [arith]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-PAT=$1; SCRIPT=$2; OUT=$3; FAM=${4:-}; SARGS=${5:-}
+PAT=$1; SCRIPT=$2; OUT=$3; FAM=${4:-}; SARGS=${5:-}; ARITHNAME=${6:-fp32}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_traffic_$c
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_traffic_$c -o p --output-format csv -- python3 $R/$SCRIPT $SARGS > $R/gpurun_out/pmc_traffic_$c.log 2>&1 || echo "$c pass failed"
 done
 cd $R
-PAT="$PAT" OUT="$OUT" FAM="$FAM" SCRIPT="$SCRIPT" python3 - <<'PY'
+PAT="$PAT" OUT="$OUT" FAM="$FAM" SCRIPT="$SCRIPT" ARITHNAME="$ARITHNAME" python3 - <<'PY'
 import csv, glob, collections, json, os
 pat = os.environ["PAT"]
 agg, name = collections.defaultdict(list), None
@@ -19,7 +19,7 @@ for f in glob.glob('gpurun_out/pmc_traffic_*/*counter_collection.csv') + glob.gl
         if pat in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
             name = r['Kernel_Name']
-res = {"kernel": name, "family": os.environ["FAM"],
+res = {"kernel": name, "family": os.environ["FAM"], "arith": os.environ["ARITHNAME"],
        "command": "bash benchmarks/pmc_traffic.sh '%s' %s  (rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE)" % (pat, os.environ["SCRIPT"])}
 for c, v in sorted(agg.items()):
     v = v[3:] if len(v) > 6 else v

@@ -848,3 +848,102 @@ def test_temporal_block_on_mfma16(mfma16_kernels, norm_type, causal, dil_x, K):
 
 def test_tiny_model_on_mfma16(mfma16_kernels):
     test_model_matches_reference_golden("model_tiny_gln")
+
+
+# ----------------------------------------------------------------------------- b3 arithmetic: kernel forms of its own
+def _raw_pw_gemm(W, X, R, Cn, K, tw, residual=None):
+    """ctn_pw_gemm through the raw C ABI (ops.pw_gemm routes b3 calls to the pre-split weight pieces)."""
+    M, _, Kp = X.shape
+    out = torch.empty((M, R, Kp), device=DEV)
+    ctn.lib.call("ctn_pw_gemm", ops._p(W), ops._p(X), ops._p(out), M, R, Cn, K, Kp, tw, None, 0, None, None, None, None,
+                 ops._p(residual), None, None, 0, ops._stream())
+    return out
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_b3_every_tile_and_weight_form(tile):
+    """b3 arithmetic: fp32 weights split on the fly (trans_w 0 / 1, pw_gemm_b3_kernel) and pre-split weight pieces
+    (trans_w 2, pw_gemm_b3p_kernel) under every tile id, ragged rows / contraction / frames, against fp64 and bitwise
+    against each other (same pieces, same product order)."""
+    if ARITH["name"] != "b3":
+        pytest.skip("b3 kernels")
+    try:
+        ctn.lib.call("ctn_tune", b"b3_tile", tile)
+        ops._ws_cache.clear()
+        for (M, R, Cn, K) in [(2, 200, 72, 515), (1, 64, 20, 130), (2, 512, 256, 1000), (3, 132, 40, 257)]:
+            Kp = ops.padded_frames(K)
+            W = torch.randn(R, Cn, generator=g(21)) * 0.3
+            X = pad(torch.randn(M, Cn, K, generator=g(22)), Kp).to(DEV)
+            res = pad(torch.randn(M, R, K, generator=g(23)), Kp).to(DEV)
+            ref = torch.einsum("oi,mik->mok", W.double(), X.double().cpu()) + res.double().cpu()
+            o0 = _raw_pw_gemm(W.to(DEV), X, R, Cn, K, 0, res)
+            o1 = _raw_pw_gemm(W.t().contiguous().to(DEV), X, R, Cn, K, 1, res)
+            o2 = _raw_pw_gemm(ops._b3_pieces(W.to(DEV), R, Cn, False), X, R, Cn, K, 2, res)
+            o3 = _raw_pw_gemm(ops._b3_pieces(W.t().contiguous().to(DEV), R, Cn, True), X, R, Cn, K, 2, res)
+            for o in (o0, o1, o2, o3):
+                assert rel_err(o[..., :K], ref[..., :K]) < 3e-6, (tile, M, R, Cn, K)
+            assert torch.equal(o0, o1) and torch.equal(o2, o3) and torch.equal(o0[..., :K], o2[..., :K])
+        # the statistics / prologue / gLN-backward forms and a block on this tile
+        test_pw_gemm_relu_and_stats_and_prologue()
+        _forward_forms_on_transposed_weights()
+        test_temporal_block_fwd_bwd("gLN", False, 3, 799)
+    finally:
+        ctn.lib.call("ctn_tune", b"b3_tile", 1)
+        ops._ws_cache.clear()
+
+
+@pytest.mark.parametrize("blocks", [64, 256, 512, 1024])
+def test_b3_weight_gradient_every_plan(blocks):
+    if ARITH["name"] != "b3":
+        pytest.skip("b3 kernels")
+    try:
+        ctn.lib.call("ctn_tune", b"b3_wgrad_blocks", blocks)
+        ops._ws_cache.clear()
+        _wgrad_plan_case()
+        for case in [(2, 64, 32, 799), (3, 512, 256, 1300), (1, 132, 72, 300)]:
+            test_pw_wgrad(*case)
+    finally:
+        ctn.lib.call("ctn_tune", b"b3_wgrad_blocks", 256)
+        ops._ws_cache.clear()
+
+
+def _wgrad_plan_case():
+    M, R, Cn, K = 3, 200, 132, 1301
+    Kp = ops.padded_frames(K)
+    dO = pad(torch.randn(M, R, K, generator=g(11)), Kp)
+    X = pad(torch.randn(M, Cn, K, generator=g(12)), Kp)
+    gam, bet = torch.randn(1, Cn, 1, generator=g(13)), torch.randn(1, Cn, 1, generator=g(14))
+    al = torch.tensor([0.2])
+    ms = torch.tensor([[0.1, 1.3], [-0.2, 0.7], [0.05, 1.1]])
+    xn = gam * ((torch.where(X >= 0, X, al * X) - ms[:, 0].view(-1, 1, 1)) * ms[:, 1].view(-1, 1, 1)) + bet
+    xn[..., K:] = 0
+    out = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K)
+    out_pro = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K, pro=(gam.to(DEV), bet.to(DEV), al.to(DEV), ms.to(DEV)))
+    assert rel_err(out, torch.einsum("mrk,mck->rc", dO.double(), X.double())) < 5e-6
+    assert rel_err(out_pro, torch.einsum("mrk,mck->rc", dO.double(), xn.double())) < 5e-6
+
+
+def test_gemm_arithmetic_switch_and_its_guards():
+    """ctn.gemm_arithmetic scopes the arithmetic; pre-split weight pieces are refused under the fp32 arithmetic and for
+    layers below 64 rows; the two arithmetics differ by no more than the b3 product precision."""
+    name = ARITH["name"]
+    assert ctn.gemm_arith() == name
+    M, R, Cn, K = 2, 128, 64, 300
+    Kp = ops.padded_frames(K)
+    W = (torch.randn(R, Cn, generator=g(31)) * 0.2).to(DEV)
+    X = pad(torch.randn(M, Cn, K, generator=g(32)), Kp).to(DEV)
+    with ctn.gemm_arithmetic("fp32"):
+        assert ctn.gemm_arith() == "fp32"
+        o32, _ = ops.pw_gemm(W, X, R, Cn, K)
+        with pytest.raises(ctn.CtnError):
+            _raw_pw_gemm(W, X, R, Cn, K, 2)
+    assert ctn.gemm_arith() == name
+    with ctn.gemm_arithmetic("b3"):
+        o3, _ = ops.pw_gemm(W, X, R, Cn, K)
+        with pytest.raises(ctn.CtnError):
+            _raw_pw_gemm(W, X[:, :Cn], 32, Cn, K, 2)          # R < 64: the fp32 kernels own this layer
+    assert ctn.gemm_arith() == name
+    ref = torch.einsum("oi,mik->mok", W.double().cpu(), X.double().cpu())
+    e32 = float((o32.double().cpu() - ref).abs().max() / ref.abs().max())
+    e3 = float((o3.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert e32 < 1e-6 and e3 < 1e-5 and not torch.equal(o32, o3)
