@@ -245,7 +245,7 @@ def roofline(rows, probe_steps):
             continue
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", pmc)))
-            if j.get("family", "")[:2] == dom["family"][:2] and j.get("arith", "fp32") == ARITH["name"]:
+            if j.get("family", "")[:2] == dom["family"][:2] and j.get("arith", "fp32") in (ARITH["name"], "any"):
                 traffic, src = j.get("hbm_bytes_per_launch"), "profiles/" + pmc
         except Exception:
             pass

@@ -5,6 +5,7 @@ MODE=${1:-kernels}
 ( while true; do echo "$(date +%s.%N) $(rocm-smi --showpower 2>/dev/null | grep -o 'Power (W): [0-9.]*' | grep -o '[0-9.]*$')"; sleep 0.15; done ) > gpurun_out/power_samples.txt &
 SP=$!
 if [ "$MODE" = mfma ]; then ./benchmarks/mfma_probe.bin 5 > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
+elif [ "$MODE" = step ]; then python benchmarks/power_lab_step.py > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
 elif [ "$MODE" = x ]; then      # split-bf16 experiments: three libraries, one process each (per-kernel sequencing for all three)
   LABEL=f32 CTN_COMPOSITE=0 python benchmarks/power_lab_x.py > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
   LABEL=x6 CTN_COMPOSITE=0 CTN_EXPERIMENTAL=1 CTN_LIB_PATH=benchmarks/lab_x6.so python benchmarks/power_lab_x.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err
@@ -19,7 +20,7 @@ for l in open("gpurun_out/power_samples.txt"):
     if len(p) == 2:
         samples.append((float(p[0]), float(p[1])))
 import os
-out = open("gpurun_out/r02_power_lab%s.txt" % {"mfma": "_mfma", "x": "_x"}.get(os.environ.get("MODE"), ""), "w")
+out = open("gpurun_out/r02_power_lab%s.txt" % {"mfma": "_mfma", "x": "_x", "step": "_step"}.get(os.environ.get("MODE"), ""), "w")
 for l in open("gpurun_out/power_cases.txt"):
     p = l.split()
     if p and p[0] == "case":
