@@ -23,7 +23,7 @@ constexpr int MAXP = 8;          // max depthwise kernel size supported
 // LDS floats per wave for the row segment (+halo).  Small buffers when the receptive field is short (more
 // workgroups per CU in flight = more HBM requests outstanding), large ones when the halo would dominate.
 constexpr int FWD_BUF_S = 1024, FWD_BUF_L = 3584;    // forward: 16 / 56 KiB per workgroup
-constexpr int BWD_BUF_S = 768, BWD_BUF_L = 1792;     // backward (two arrays): 24 / 56 KiB per workgroup
+constexpr int BWD_BUF_S = 768, BWD_BUF_M = 1280, BWD_BUF_L = 1792;     // backward (two arrays): 24 / 40 / 56 KiB per workgroup
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ int floor4(int v) { return (v >> 2) << 2; }  // arithmetic shift: floors negatives
@@ -1120,8 +1120,10 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     CTN_REQUIRE(aligned16(dN2) && aligned16(Y1) && aligned16(dN1) && (!fused || aligned16(Dz)), "ctn_dw_bwd: alignment");
     const int halo = (P - 1) * dilation;
     CTN_REQUIRE(causal || halo % 2 == 0, "ctn_dw_bwd: non-causal 'same' padding needs (P-1)*dilation even");
-    const bool small = halo <= 128;
-    const int seg = (((small ? BWD_BUF_S : BWD_BUF_L) - halo - 8) / 64) * 64;
+    // patch size by halo: the dilation-128 blocks of the paper stack (halo 256) ran at 107 us with the 1792-float patches
+    // (2 workgroups per CU) against 52 us for the others; 1280 floats = 960-frame segments at 4 workgroups per CU
+    const bool small = halo <= 128, medium = !small && halo <= 256;
+    const int seg = (((small ? BWD_BUF_S : (medium ? BWD_BUF_M : BWD_BUF_L)) - halo - 8) / 64) * 64;
     CTN_REQUIRE(seg >= 64, "ctn_dw_bwd: receptive field (P-1)*dilation=%d too large", halo);
     if (fused)
         CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && sums1_part,
@@ -1140,6 +1142,8 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     do {                                                                                                        \
         if (small && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, true, PT_>), grid, block, 0, st, a);      \
         else if (small) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, false, PT_>), grid, block, 0, st, a);        \
+        else if (medium && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_M, true, PT_>), grid, block, 0, st, a);  \
+        else if (medium) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_M, false, PT_>), grid, block, 0, st, a);       \
         else if (vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, true, PT_>), grid, block, 0, st, a);          \
         else hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, false, PT_>), grid, block, 0, st, a);                   \
     } while (0)
