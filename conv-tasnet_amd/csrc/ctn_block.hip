@@ -15,6 +15,7 @@
 #include <vector>
 
 extern "C" int ctn_pw_uses_pk(void);       // ctn_gemm.hip
+int g_ctn_block_fin_side = 1;            // ctn_tune("fin_side", 0): parameter-gradient sums on the chain's stream (A/B runs)
 int g_ctn_block_wt = 1;                     // ctn_tune("block_wt", 0): forward GEMMs on the stored [O, I] weights (A/B runs)
 
 namespace {
@@ -79,7 +80,7 @@ FwdWs fwd_ws(int M, int B, int H, int Kp, int nblocks) {
 }
 
 struct BwdWs {
-    size_t dn2, s2p, s1p, pc, da1p, slab, wp, total;
+    size_t dn2, s2p, s1p, pc, da1p, slab, wp, total, pc_slot, da1p_slot;
     size_t slab_bytes;
     int np2;
 };
@@ -90,8 +91,11 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.dn2 = o; o += align256((size_t)M * H * Kp * sizeof(float));
     w.s2p = o; o += align256((size_t)M * w.np2 * 2 * sizeof(double));
     w.s1p = o; o += align256((size_t)M * H * 2 * sizeof(double));
-    w.pc = o; o += align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
-    w.da1p = o; o += align256((size_t)M * H * sizeof(float));
+    // per-block slots: the finalize kernel of block i runs on the weight-gradient stream while the chain is already in block i-1
+    w.pc_slot = align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
+    w.da1p_slot = align256((size_t)M * H * sizeof(float));
+    w.pc = o; o += (size_t)nblocks * w.pc_slot;
+    w.da1p = o; o += (size_t)nblocks * w.da1p_slot;
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
     w.slab_bytes = s1 > s2 ? s1 : s2;
     w.slab = o; o += align256(w.slab_bytes);
@@ -178,11 +182,9 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     float* const dn2 = (float*)(ws + w.dn2);
     double* const s2p = (double*)(ws + w.s2p);
     double* const s1p = (double*)(ws + w.s1p);
-    float* const pc = (float*)(ws + w.pc);
-    float* const da1p = (float*)(ws + w.da1p);
     void* const slab = ws + w.slab;
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
-    void* const wst = side_stream ? side_stream : stream;       // where the weight gradients go
+    void* const wst = side_stream ? side_stream : stream;       // where the weight gradients (and parameter-gradient sums) go
     int rc;
     for (int i = 0; i < nblocks; ++i)
         for (int j = 0; j < NPARAM; ++j)
@@ -203,6 +205,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;   // gradient of this block's output
         float* const dx = dxs + (size_t)i * xsz;
         float* const dn1 = dn1s + (size_t)i * hsz;      // a slot per block: the side stream still reads it while the chain moves on
+        float* const pc = (float*)(ws + w.pc + (size_t)i * w.pc_slot);
+        float* const da1p = (float*)(ws + w.da1p + (size_t)i * w.da1p_slot);
         // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
         if (twh == 2) rc = ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
         else rc = ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
@@ -216,10 +220,11 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         if (rc) return rc;
         rc = ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream);
         if (rc) return rc;
-        rc = ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, M * H, g[P_A1], stream);
-        if (rc) return rc;
-        // first 1x1
+        // first 1x1; the fixed-order sums of this block's parameter-gradient partials feed only the optimiser: second stream too
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        rc = ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, M * H, g[P_A1],
+                                 g_ctn_block_fin_side ? wst : stream);
+        if (rc) return rc;
         if (side_stream) {
             rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
             if (rc) return rc;
@@ -241,7 +246,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
 // ---- cLN stack (causal BASELINE config): the same host-side composite over the un-fused norm kernels ------------------
 namespace {
 struct ClnBwdWs {
-    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, total, slab_bytes;
+    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, total, slab_bytes, pcw_slot, pcn_slot, dap_slot;
 };
 ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     ClnBwdWs w;
@@ -250,9 +255,14 @@ ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.dn2 = o; o += hsz;
     w.dd = o; o += hsz;
     w.dn1 = o; o += hsz;
-    w.pcw = o; o += align256((size_t)P * M * H * sizeof(float));
-    w.pcn = o; o += align256(ctn_cln_bwd_pc_floats(M, H, Kp) * sizeof(float));
-    w.dap = o; o += align256((size_t)ctn_cln_bwd_blocks(M, Kp) * sizeof(float));
+    // parameter-gradient partials: a slot per block (two per block for the norms) -- their fixed-order sums run on the
+    // weight-gradient stream while the chain is already in the next block
+    w.pcw_slot = align256((size_t)P * M * H * sizeof(float));
+    w.pcn_slot = align256(ctn_cln_bwd_pc_floats(M, H, Kp) * sizeof(float));
+    w.dap_slot = align256((size_t)ctn_cln_bwd_blocks(M, Kp) * sizeof(float));
+    w.pcw = o; o += (size_t)nblocks * w.pcw_slot;
+    w.pcn = o; o += (size_t)nblocks * 2 * w.pcn_slot;
+    w.dap = o; o += (size_t)nblocks * 2 * w.dap_slot;
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
     w.slab_bytes = s1 > s2 ? s1 : s2;
     w.slab = o; o += align256(w.slab_bytes);
@@ -324,9 +334,6 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     float* const dn2 = (float*)(ws + w.dn2);
     float* const dd = (float*)(ws + w.dd);
     float* const dn1 = (float*)(ws + w.dn1);
-    float* const pcw = (float*)(ws + w.pcw);
-    float* const pcn = (float*)(ws + w.pcn);
-    float* const dap = (float*)(ws + w.dap);
     void* const slab = ws + w.slab;
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
     void* const wst = side_stream ? side_stream : stream;
@@ -348,18 +355,23 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;
         float* const dx = dxs + (size_t)i * xsz;
         float* const dh1 = dh1s + (size_t)i * hsz;          // a slot per block: the side stream reads it while the chain moves on
+        float* const pcw = (float*)(ws + w.pcw + (size_t)i * w.pcw_slot);
+        float* const pcn2 = (float*)(ws + w.pcn + (size_t)(2 * i) * w.pcn_slot), * const pcn1 = (float*)(ws + w.pcn + (size_t)(2 * i + 1) * w.pcn_slot);
+        float* const dap2 = (float*)(ws + w.dap + (size_t)(2 * i) * w.dap_slot), * const dap1 = (float*)(ws + w.dap + (size_t)(2 * i + 1) * w.dap_slot);
         if ((rc = ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         if ((rc = ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
-        if ((rc = ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap, pcn, stream))) return rc;
-        if ((rc = ctn_cln_bwd_finalize(pcn, dap, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], stream))) return rc;
+        if ((rc = ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, stream))) return rc;
         if ((rc = ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream))) return rc;
-        if ((rc = ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], stream))) return rc;
-        if ((rc = ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap, pcn, stream))) return rc;
-        if ((rc = ctn_cln_bwd_finalize(pcn, dap, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], stream))) return rc;
+        if ((rc = ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, stream))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        // the three fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
+        void* const fst = g_ctn_block_fin_side ? wst : stream;
+        if ((rc = ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst))) return rc;
+        if ((rc = ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst))) return rc;
+        if ((rc = ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst))) return rc;
         if (side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
         if ((rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream))) return rc;

@@ -843,7 +843,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 #include "ctn_gemm_b3.h"            // the split-bf16 ("b3") arithmetic of the same GEMMs
 
 int g_ctn_tile_override = -2;
-extern int g_ctn_block_wt;          // ctn_block.hip
+extern int g_ctn_block_wt, g_ctn_block_fin_side;          // ctn_block.hip
 
 // GEMM arithmetic: 0 = fp32 MFMA (bit-exact fp32 FMA chains), 1 = "b3" (two bf16 pieces per operand, three bf16 MFMAs,
 // fp32 accumulation: ctn_gemm_b3.h).  CTN_GEMM_ARITH=fp32|b3, ctn_tune("arith", 0|1).  Layers with fewer than 64 output
@@ -1154,6 +1154,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_kernel")) g_w4 = value ? 1 : 0;
     else if (!strcmp(key, "pw_tile") && value >= -1 && value <= 11) g_ctn_tile_override = value;
     else if (!strcmp(key, "block_wt")) g_ctn_block_wt = value ? 1 : 0;
+    else if (!strcmp(key, "fin_side")) g_ctn_block_fin_side = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_mf") && (value == 16 || value == 32)) g_w4_mf = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
     else if (!strcmp(key, "arith") && (value == 0 || value == 1)) g_arith = value;
