@@ -27,6 +27,53 @@ __global__ __launch_bounds__(NT) void im2col_kernel(const float* __restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Encoder, src/conv_tasnet.py:106-121:  w[m, n, k] = relu( sum_l U[n, l] * mix[m, k*S + l] ),  S = L/2  (Conv1d(1, N, L, stride
+// L/2, bias=False) + ReLU), zero for frames k >= K.  HBM-bound on its output (M*N*K*4 bytes; the input is 1/N of that):
+// the L-sample sliding windows of a block of 256 frames are staged in LDS once (256*S + S samples, coalesced) together
+// with the basis rows of this workgroup's 64 channels; lane = frame, so every output store of a wave is 256 contiguous
+// bytes along the frame axis; a basis row is read as broadcast float4s.  No im2col buffer on the forward path.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int ENC_FR = 256, ENC_CH = 64;
+template <int L>
+__global__ __launch_bounds__(ENC_FR) void encoder_fwd_kernel(const float* __restrict__ mix, const float* __restrict__ U,
+                                                            float* __restrict__ w, int T, int N, int K, int Kp) {
+    constexpr int S = L / 2;
+    __shared__ __attribute__((aligned(16))) float win[ENC_FR * S + L];
+    __shared__ __attribute__((aligned(16))) float ub[ENC_CH * L];
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * ENC_FR, n0 = blockIdx.y * ENC_CH, m = blockIdx.z;
+    const float* __restrict__ x = mix + (size_t)m * T;
+    for (int i = tid; i < ENC_FR * S + L; i += ENC_FR) {
+        const int t = k0 * S + i;
+        win[i] = t < T ? x[t] : 0.f;
+    }
+    for (int i = tid; i < ENC_CH * L; i += ENC_FR) {
+        const int n = n0 + i / L;
+        ub[i] = n < N ? U[(size_t)n * L + i % L] : 0.f;
+    }
+    __syncthreads();
+    const int k = k0 + tid;
+    float xv[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) xv[l] = win[tid * S + l];
+    if (k >= Kp) return;
+    const bool valid = k < K;
+    float* __restrict__ out = w + ((size_t)m * N + n0) * Kp + k;
+    for (int c = 0; c < ENC_CH && n0 + c < N; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int l4 = 0; l4 < L / 4; ++l4) {
+            const float4 u = *reinterpret_cast<const float4*>(ub + c * L + 4 * l4);       // same address in every lane: broadcast
+            acc = fmaf(u.x, xv[4 * l4 + 0], acc);
+            acc = fmaf(u.y, xv[4 * l4 + 1], acc);
+            acc = fmaf(u.z, xv[4 * l4 + 2], acc);
+            acc = fmaf(u.w, xv[4 * l4 + 3], acc);
+        }
+        out[(size_t)c * Kp] = valid ? fmaxf(acc, 0.f) : 0.f;
+    }
+}
+
 // sw[m,c,n,k] = w[m,n,k] * act(score[m,c,n,k]);  act = relu (mode 0), softmax over c (mode 1) or identity (mode 2: the
 // stand-alone Decoder.forward, whose est_mask argument already is a mask, src/conv_tasnet.py:140)
 __global__ __launch_bounds__(NT) void mask_apply_kernel(const float* __restrict__ score, const float* __restrict__ w,
@@ -236,6 +283,24 @@ int ctn_im2col(const float* mix, float* xcol, int M, int T, int L, int Lp, int K
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((long long)M * Lp * Kp)), dim3(NT), 0, (hipStream_t)stream,
                        mix, xcol, M, T, L, Lp, L / 2, K, Kp);
     CTN_CHECK_LAUNCH("ctn_im2col");
+    return CTN_OK;
+}
+
+int ctn_encoder_supported(int L) { return L == 16 || L == 20 || L == 32 || L == 40; }
+
+int ctn_encoder_fwd(const float* mix, const float* U, float* w, int M, int T, int N, int L, int K, int Kp, void* stream) {
+    CTN_REQUIRE(mix && U && w, "ctn_encoder_fwd: null pointer");
+    CTN_REQUIRE(ctn_encoder_supported(L), "ctn_encoder_fwd: filter length %d not compiled in (16, 20, 32, 40): use ctn_im2col + ctn_pw_gemm", L);
+    CTN_REQUIRE(M > 0 && N > 0 && T >= L && K == (T - L) / (L / 2) + 1 && Kp >= K, "ctn_encoder_fwd: inconsistent sizes (T=%d L=%d K=%d Kp=%d)", T, L, K, Kp);
+    const dim3 grid((unsigned)ctn_cdiv(Kp, ENC_FR), (unsigned)ctn_cdiv(N, ENC_CH), (unsigned)M), block(ENC_FR);
+    hipStream_t st = (hipStream_t)stream;
+    switch (L) {
+        case 16: hipLaunchKernelGGL(encoder_fwd_kernel<16>, grid, block, 0, st, mix, U, w, T, N, K, Kp); break;
+        case 20: hipLaunchKernelGGL(encoder_fwd_kernel<20>, grid, block, 0, st, mix, U, w, T, N, K, Kp); break;
+        case 32: hipLaunchKernelGGL(encoder_fwd_kernel<32>, grid, block, 0, st, mix, U, w, T, N, K, Kp); break;
+        default: hipLaunchKernelGGL(encoder_fwd_kernel<40>, grid, block, 0, st, mix, U, w, T, N, K, Kp); break;
+    }
+    CTN_CHECK_LAUNCH("ctn_encoder_fwd");
     return CTN_OK;
 }
 

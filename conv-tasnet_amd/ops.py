@@ -371,14 +371,19 @@ class Frontend(torch.autograd.Function):
         if K < 1:
             raise ValueError("mixture of %d samples is shorter than one encoder frame (L=%d)" % (T, L))
         mix = _c(mix.to(F32))
-        xcol = torch.empty((M, L, Kp), dtype=F32, device=mix.device)
         _chk(mix, U, g0, b0, Wb)
-        lib.call("ctn_im2col", _p(mix), _p(xcol), M, T, L, L, K, Kp, _stream())
-        w, _ = pw_gemm(U, xcol, N, L, K, relu_out=True)
+        if lib.ctn_encoder_supported(L):        # sliding windows staged in LDS, no im2col buffer (the backward pass unfolds)
+            xcol = None
+            w = torch.empty((M, N, Kp), dtype=F32, device=mix.device)
+            lib.call("ctn_encoder_fwd", _p(mix), _p(_c(U)), _p(w), M, T, N, L, K, Kp, _stream())
+        else:
+            xcol = torch.empty((M, L, Kp), dtype=F32, device=mix.device)
+            lib.call("ctn_im2col", _p(mix), _p(xcol), M, T, L, L, K, Kp, _stream())
+            w, _ = pw_gemm(U, xcol, N, L, K, relu_out=True)
         y0, mean0, rstd0 = cln_fwd(w, g0, b0, None, K)
         x0, _ = pw_gemm(Wb, y0, B, N, K)
-        ctx.save_for_backward(xcol, w, y0, mean0, rstd0, U, g0, Wb)
-        ctx.K = K
+        ctx.save_for_backward(mix if xcol is None else xcol, w, y0, mean0, rstd0, U, g0, Wb)
+        ctx.K, ctx.T, ctx.unfolded = K, T, xcol is not None
         ctx.sinks = (_sink(U), _sink(g0), _sink(b0), _sink(Wb))
         ctx.set_materialize_grads(False)
         return w, x0
@@ -390,6 +395,9 @@ class Frontend(torch.autograd.Function):
         M, N, Kp = w.shape
         B = Wb.shape[0]
         L = U.shape[-1]
+        if not ctx.unfolded:                    # saved the mixture itself: unfold it now for the basis gradient (2 MB)
+            mix, xcol = xcol, torch.empty((M, L, Kp), dtype=F32, device=w.device)
+            lib.call("ctn_im2col", _p(mix), _p(xcol), M, ctx.T, L, L, K, Kp, _stream())
         if dx0 is None:
             dx0 = torch.zeros((M, B, Kp), dtype=F32, device=w.device)
         dx0 = _c(dx0)

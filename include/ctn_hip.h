@@ -247,10 +247,16 @@ int ctn_bn_bwd(const float* dOut, const float* Y, float* dY, const float* alpha,
 int ctn_reduce_mid(const float* in, float* out, int F, int Mid, int Inner, void* stream);
 
 /* ---- encoder / decoder glue -----------------------------------------------------------
- * encoder  src/conv_tasnet.py:106-121 : ctn_im2col + ctn_pw_gemm(relu_out=1)
+ * encoder  src/conv_tasnet.py:106-121 : ctn_encoder_fwd (forward); ctn_im2col + ctn_pw_wgrad (basis gradient)
  * decoder  src/conv_tasnet.py:140-145 : ctn_mask_apply + ctn_pw_gemm + ctn_ola (src/utils.py:9-47)
  * mask non-linearity src/conv_tasnet.py:208-214 (relu | softmax over speakers). */
 int ctn_im2col(const float* mix, float* xcol, int M, int T, int L, int Lp, int K, int Kp, void* stream);
+/* The encoder in one kernel (forward): w[m,n,k] = relu(sum_l U[n,l] * mix[m, k*L/2 + l]), zero for k >= K; the L-sample
+ * sliding windows of 256 frames and the basis rows are staged in LDS, no im2col buffer.  U: [N, L] (the Conv1d weight
+ * [N,1,L]); w: [M,N,Kp].  Filter lengths compiled in: ctn_encoder_supported(L) (16, 20, 32, 40); other lengths and the
+ * weight gradient use ctn_im2col + the GEMM entry points. */
+int ctn_encoder_supported(int L);
+int ctn_encoder_fwd(const float* mix, const float* U, float* w, int M, int T, int N, int L, int K, int Kp, void* stream);
 /* softmax: 0 = relu, 1 = softmax over speakers, 2 = identity (sw = w * score: the stand-alone Decoder.forward, :140) */
 int ctn_mask_apply(const float* score, const float* w, float* sw, int M, int C, int N, int Kp, int softmax, void* stream);
 int ctn_mask_apply_bwd(const float* dsw, const float* score, const float* w, float* dscore, float* dw,

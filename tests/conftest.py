@@ -27,10 +27,12 @@ def golden():
 # ---- GEMM arithmetic: the GPU suites run under both -------------------------------------------------------------------
 # "b3" (library default): two bf16 pieces per fp32 operand, three bf16 MFMAs, fp32 accumulation (products carry >= 16
 # significand bits); "fp32": fp32-MFMA kernels (bit-exact fp32 FMA chains).  Tensor tolerances in the GPU tests are
-# written for fp32 and widened by TOL_SCALE under b3 (its dot products measure 6.5x the fp32 error against fp64,
-# benchmarks/b3_check.py); the decibel budgets (1e-3 dB, north star) are absolute and NOT widened.
+# written for fp32 and widened by TOL_SCALE under b3: its dot products measure 6.5x the fp32 error against fp64
+# (benchmarks/b3_check.py), and the ill-conditioned sums of the deep models (norm-parameter gradients of the paper-size
+# causal stack: fp32-GPU against the fp32-CPU oracle already differ by 5e-3 of the largest element) see up to ~10x.
+# A single bf16 product would be 500x.  The decibel budgets (1e-3 dB, north star) are absolute and NOT widened.
 ARITH = {"name": "fp32"}
-TOL_SCALE = {"fp32": 1.0, "b3": 8.0}
+TOL_SCALE = {"fp32": 1.0, "b3": 16.0}
 
 
 def tol_scale():

@@ -20,7 +20,7 @@ DEV = "cuda:0"
 
 
 def rel_err(got, ref):
-    """max |got - ref| / max |ref|, divided by the arithmetic's tolerance scale (1 for fp32-MFMA, 8 for b3): the limits
+    """max |got - ref| / max |ref|, divided by the arithmetic's tolerance scale (1 for fp32-MFMA, 16 for b3): the limits
     asserted below are the fp32 ones."""
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
@@ -452,7 +452,8 @@ def _config_parity(cfg, M, T, seed, grad_tol=5e-3):
     for k, p in m.named_parameters():
         ref = sd[k].grad
         err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
-        assert err < grad_tol, (k, err)
+        # (b3 arithmetic: 4x the fp32 limit -- observed 6e-3 on one cLN gain of the paper-size causal stack, 3e-3 under fp32)
+        assert err < grad_tol * min(tol_scale(), 4.0), (k, err)
         worst = max(worst, err)
     return worst
 
@@ -947,3 +948,21 @@ def test_gemm_arithmetic_switch_and_its_guards():
     e32 = float((o32.double().cpu() - ref).abs().max() / ref.abs().max())
     e3 = float((o3.double().cpu() - ref).abs().max() / ref.abs().max())
     assert e32 < 1e-6 and e3 < 1e-5 and not torch.equal(o32, o3)
+
+
+@pytest.mark.parametrize("L,N,T,M", [(20, 256, 8000, 2), (16, 72, 3001, 3), (32, 64, 5000, 1), (40, 100, 4444, 2)])
+def test_encoder_kernel_matches_conv1d(L, N, T, M):
+    """ctn_encoder_fwd (sliding windows staged in LDS, no im2col buffer) against torch's Conv1d(1, N, L, stride L/2) + ReLU
+    in fp64 (src/conv_tasnet.py:106-121): ragged frame count, channel counts that do not fill the 64-channel block."""
+    K = (T - L) // (L // 2) + 1
+    Kp = ops.padded_frames(K)
+    mix = torch.randn(M, T, generator=g(41))
+    U = torch.randn(N, 1, L, generator=g(42)) * 0.3
+    ref = torch.relu(torch.nn.functional.conv1d(mix.double().unsqueeze(1), U.double(), stride=L // 2))
+    w = torch.full((M, N, Kp), 7.0, device=DEV)
+    mix_d, U_d = mix.to(DEV), U.to(DEV)          # (named: a temporary's memory may be recycled before the kernel runs)
+    ctn.lib.call("ctn_encoder_fwd", ops._p(mix_d), ops._p(U_d), ops._p(w), M, T, N, L, K, Kp, ops._stream())
+    assert rel_err(w[..., :K], ref) * tol_scale() < 2e-6            # fp32 FMA chains under either GEMM arithmetic
+    assert float(w[..., K:].abs().max()) == 0.0
+    with pytest.raises(ctn.CtnError):
+        ctn.lib.call("ctn_encoder_fwd", ops._p(mix_d), ops._p(U_d), ops._p(w), M, T, N, 24, K, Kp, ops._stream())
