@@ -15,6 +15,8 @@
 #include <vector>
 
 extern "C" int ctn_pw_uses_pk(void);       // ctn_gemm.hip
+int g_ctn_block_fuse_b4 = 0;             // ctn_tune("fuse_b4", 1): gln_prelu_bwd folded into its two consumers (b3): bitwise the
+                                         // same gradients, measured 10.23 vs 10.13 ms per step -> off by default
 int g_ctn_block_fin_side = 1;            // ctn_tune("fin_side", 0): parameter-gradient sums on the chain's stream (A/B runs)
 int g_ctn_block_wt = 1;                     // ctn_tune("block_wt", 0): forward GEMMs on the stored [O, I] weights (A/B runs)
 
@@ -80,7 +82,7 @@ FwdWs fwd_ws(int M, int B, int H, int Kp, int nblocks) {
 }
 
 struct BwdWs {
-    size_t dn2, s2p, s1p, pc, da1p, slab, wp, total, pc_slot, da1p_slot;
+    size_t dn2, s2p, s1p, pc, da1p, slab, wp, total, pc_slot, da1p_slot, s1p_slot;
     size_t slab_bytes;
     int np2;
 };
@@ -90,7 +92,8 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     size_t o = 0;
     w.dn2 = o; o += align256((size_t)M * H * Kp * sizeof(float));
     w.s2p = o; o += align256((size_t)M * w.np2 * 2 * sizeof(double));
-    w.s1p = o; o += align256((size_t)M * H * 2 * sizeof(double));
+    w.s1p_slot = align256((size_t)M * H * 2 * sizeof(double));        // per block: the fused weight gradient of the second stream reads it
+    w.s1p = o; o += (size_t)nblocks * w.s1p_slot;
     // per-block slots: the finalize kernel of block i runs on the weight-gradient stream while the chain is already in block i-1
     w.pc_slot = align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
     w.da1p_slot = align256((size_t)M * H * sizeof(float));
@@ -181,7 +184,6 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     char* const ws = (char*)workspace;
     float* const dn2 = (float*)(ws + w.dn2);
     double* const s2p = (double*)(ws + w.s2p);
-    double* const s1p = (double*)(ws + w.s1p);
     void* const slab = ws + w.slab;
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
     void* const wst = side_stream ? side_stream : stream;       // where the weight gradients (and parameter-gradient sums) go
@@ -207,6 +209,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         float* const dn1 = dn1s + (size_t)i * hsz;      // a slot per block: the side stream still reads it while the chain moves on
         float* const pc = (float*)(ws + w.pc + (size_t)i * w.pc_slot);
         float* const da1p = (float*)(ws + w.da1p + (size_t)i * w.da1p_slot);
+        double* const s1p = (double*)(ws + w.s1p + (size_t)i * w.s1p_slot);
         // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
         if (twh == 2) rc = ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
         else rc = ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
@@ -218,23 +221,39 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         rc = ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
                         p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream);
         if (rc) return rc;
-        rc = ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream);
-        if (rc) return rc;
-        // first 1x1; the fixed-order sums of this block's parameter-gradient partials feed only the optimiser: second stream too
-        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        rc = ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, M * H, g[P_A1],
-                                 g_ctn_block_fin_side ? wst : stream);
-        if (rc) return rc;
-        if (side_stream) {
-            rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
+        // gLN1' / PReLU1' backward: its own pass (B4), or -- opt-in, b3 arithmetic -- folded into the prologues of its two
+        // consumers (dn1 stays the raw gradient; the 157 MB pass and its launch leave the chain, the two GEMMs read h1 too)
+        const bool fused = g_ctn_block_fuse_b4 && twb == 2 && ctn_gemm_arith() == 1 && H >= 32 && B >= 32;
+        int n_da1 = M * H;
+        if (!fused) {
+            rc = ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream);
             if (rc) return rc;
+        } else {
+            n_da1 = ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp);
         }
-        rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
-                         nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream);
+        // first 1x1; the weight gradient and the fixed-order sums of this block's parameter-gradient partials feed only the
+        // optimiser: second stream
+        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        auto wgrad1 = [&]() -> int {
+            if (fused) return ctn_pw_wgrad_glnbwd(dn1, h1, x, g[P_W1], M, H, B, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, da1p, slab, w.slab_bytes, wst);
+            return ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
+        };
+        auto finalize = [&](void* st) -> int {
+            return ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st);
+        };
+        if (side_stream) {          // (the fused weight gradient produces the PReLU-slope partials: finalize after it)
+            if ((rc = wgrad1())) return rc;
+            if ((rc = finalize(g_ctn_block_fin_side || fused ? wst : stream))) return rc;
+        }
+        if (fused)
+            rc = ctn_pw_gemm_glnbwd(wreg + (size_t)(2 * i + 1) * slot, dn1, h1, dx, M, B, H, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, dy, stream);
+        else
+            rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                             nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream);
         if (rc) return rc;
         if (!side_stream) {
-            rc = ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
-            if (rc) return rc;
+            if ((rc = wgrad1())) return rc;
+            if ((rc = finalize(stream))) return rc;
         }
     }
     if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;

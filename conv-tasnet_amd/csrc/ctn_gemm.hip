@@ -843,7 +843,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 #include "ctn_gemm_b3.h"            // the split-bf16 ("b3") arithmetic of the same GEMMs
 
 int g_ctn_tile_override = -2;
-extern int g_ctn_block_wt, g_ctn_block_fin_side;          // ctn_block.hip
+extern int g_ctn_block_wt, g_ctn_block_fin_side, g_ctn_block_fuse_b4;          // ctn_block.hip
 
 // GEMM arithmetic: 0 = fp32 MFMA (bit-exact fp32 FMA chains), 1 = "b3" (two bf16 pieces per operand, three bf16 MFMAs,
 // fp32 accumulation: ctn_gemm_b3.h).  CTN_GEMM_ARITH=fp32|b3, ctn_tune("arith", 0|1).  Layers with fewer than 64 output
@@ -1155,6 +1155,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "pw_tile") && value >= -1 && value <= 11) g_ctn_tile_override = value;
     else if (!strcmp(key, "block_wt")) g_ctn_block_wt = value ? 1 : 0;
     else if (!strcmp(key, "fin_side")) g_ctn_block_fin_side = value ? 1 : 0;
+    else if (!strcmp(key, "fuse_b4")) g_ctn_block_fuse_b4 = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_mf") && (value == 16 || value == 32)) g_w4_mf = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
     else if (!strcmp(key, "arith") && (value == 0 || value == 1)) g_arith = value;
@@ -1242,6 +1243,54 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     const long long n = (long long)R * Cn;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n / 4, NT)), block, 0, st, a.slab, nsplit, n, dW);   // R, Cn multiples of 4
     CTN_CHECK_LAUNCH("ctn_pw_wgrad/reduce");
+    return CTN_OK;
+}
+// ---- the gLN'/PReLU' backward pass folded into its two consumers (b3 arithmetic, pre-split weights): see include/ctn_hip.h
+int ctn_pw_gemm_glnbwd(const void* Wp, const float* dN, const float* y, float* Out, int M, int R, int Cn, int K, int Kp,
+                       const double* sums_part, int nparts, const float* gamma, const float* alpha, const float* ms,
+                       const float* residual, void* stream) {
+    int rc = check_common("ctn_pw_gemm_glnbwd", (const float*)Wp, dN, Out, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(y && sums_part && nparts > 0 && gamma && alpha && ms && residual, "ctn_pw_gemm_glnbwd: null pointer");
+    CTN_REQUIRE(aligned16(y) && aligned16(residual), "ctn_pw_gemm_glnbwd: alignment");
+    CTN_REQUIRE(b3_fwd(R), "ctn_pw_gemm_glnbwd: needs the b3 arithmetic and R >= 64");
+    PwArgs a{};
+    a.store_f32 = 1;
+    a.W = (const float*)Wp; a.X = dN; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.pro_part = sums_part; a.pro_nparts = nparts; a.pro_gamma = gamma; a.pro_alpha = alpha; a.pro_ms = ms; a.pro_y = y;
+    a.residual = residual;
+    ctn_b3_launch_fwd(a, 2, false, true, false, false, false, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_gemm_glnbwd");
+    return CTN_OK;
+}
+
+int ctn_pw_wgrad_glnbwd_parts(int M, int R, int Cn, int Kp) {
+    int chunk, cpm;
+    ctn_b3_wgrad_plan(M, R, Cn, Kp, &chunk, &cpm);
+    return M * cpm * ctn_cdiv(R, BM);
+}
+
+int ctn_pw_wgrad_glnbwd(const float* dN, const float* y, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                        const double* sums_part, int nparts, const float* gamma, const float* alpha, const float* ms,
+                        float* dalpha_part, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("ctn_pw_wgrad_glnbwd", dW, X, dN, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(y && sums_part && nparts > 0 && gamma && alpha && ms && dalpha_part && aligned16(y), "ctn_pw_wgrad_glnbwd: bad arguments");
+    CTN_REQUIRE(b3_wgrad(R, Cn), "ctn_pw_wgrad_glnbwd: needs the b3 arithmetic and R, Cn >= 32");
+    WgArgs a{};
+    a.dOut = dN; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.a_y = y; a.a_gamma = gamma; a.a_alpha = alpha; a.a_ms = ms; a.a_part = sums_part; a.a_nparts = nparts; a.dalpha_part = dalpha_part;
+    ctn_b3_wgrad_plan(M, R, Cn, Kp, &a.chunk, &a.chunks_per_m);
+    const size_t need = (size_t)M * a.chunks_per_m * R * Cn * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) {
+        ctn_set_error("ctn_pw_wgrad_glnbwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return CTN_ERR_WORKSPACE;
+    }
+    const int ns = ctn_b3_launch_wgrad(a, false, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_wgrad_glnbwd");
+    const long long nn = (long long)R * Cn;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);
+    CTN_CHECK_LAUNCH("ctn_pw_wgrad_glnbwd/reduce");
     return CTN_OK;
 }
 }  // extern "C"

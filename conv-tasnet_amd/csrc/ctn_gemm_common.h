@@ -13,7 +13,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
 
-enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
+enum { PRO_NONE = 0, PRO_PRELU_NORM = 1, PRO_GLN_BWD = 2 };
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4 };
 
 // Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
@@ -63,6 +63,11 @@ struct PwArgs {
     const double* pro_part; int pro_nparts;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha;
     float* pro_ms_out;   // [M,2] (mean, rstd) for the backward pass, optional
+    // PRO_GLN_BWD (b3 kernel on pre-split weights): the operand is gLN'/PReLU' applied on the fly to X = dN (gradient with
+    // respect to the norm's output):  x' = rstd*(gamma[i]*dN - S1/n - xh*S2/n) * prelu'(y),  xh = (prelu(y) - mean)*rstd,
+    // y = pro_y [M,Cn,Kp] the norm's pre-activation input, (mean, rstd) = pro_ms [M,2], (S1, S2) = sums of the
+    // [M, pro_nparts, 2] fp64 partials in pro_part, n = Cn*K; pro_gamma, pro_alpha as above.  0 for frames k >= K.
+    const float* pro_y; const float* pro_ms;
     // epilogues
     const float* residual;                         // EPI_RESIDUAL: [M,R,Kp]
     const float* epi_alpha; double* epi_part;      // EPI_PRELU_STATS: [M, tiles_r*tiles_c, 2]
@@ -117,6 +122,32 @@ __device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, flo
         if (k + 3 >= K) v.w = 0.f;
     }
     return v;
+}
+
+// gLN'/PReLU' backward of one element (the arithmetic of gln_prelu_bwd_kernel, ctn_tcn.hip, bit for bit):
+//   q = {rstd, alpha*rstd, mean*rstd, rstd*S1/n, rstd*S2/n, alpha};  rg = rstd*gamma[channel];  returns dY, adds to dal
+struct GlnBwdQ { float rstd, ar, mr, rc1, rc2, al; };
+__device__ __forceinline__ float gln_bwd_elem(float dn, float y, float rg, const GlnBwdQ& q, bool valid, float& dal) {
+    const float xh = fmaf(y, y >= 0.f ? q.rstd : q.ar, -q.mr);
+    const float da = fmaf(-xh, q.rc2, fmaf(rg, dn, -q.rc1));
+    if (valid && y < 0.f) dal += da * y;
+    return valid ? (y >= 0.f ? da : q.al * da) : 0.f;
+}
+// the uniform part: sums of the fp64 partials of utterance m (fixed order), every thread of the block gets the same values
+template <int NTH>
+__device__ __forceinline__ GlnBwdQ gln_bwd_uniform(const double* __restrict__ part, int nparts, int m, double count,
+                                                   const float* __restrict__ ms, const float* __restrict__ alpha, double* red) {
+    double S1 = 0.0, S2 = 0.0;
+    if (threadIdx.x < 256)              // 256 strided partial sums whatever the block size: the bits of gln_prelu_bwd_kernel
+        for (int i = threadIdx.x; i < nparts; i += 256) {
+            S1 += part[((size_t)m * nparts + i) * 2];
+            S2 += part[((size_t)m * nparts + i) * 2 + 1];
+        }
+    S1 = block_sum<double, NTH>(S1, red);
+    S2 = block_sum<double, NTH>(S2, red);
+    const float c1 = (float)(S1 / count), c2 = (float)(S2 / count);
+    const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha[0];
+    return GlnBwdQ{rstd, al * rstd, mean * rstd, rstd * c1, rstd * c2, al};
 }
 
 // exact 3-way bf16 split of an fp32 value: v = a + b + c, 8 significand bits each
@@ -273,6 +304,11 @@ struct WgArgs {
     int M, R, Cn, K, Kp;
     int tiles_r, tiles_c, chunk, chunks_per_m;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
+    // b3 kernel: gLN'/PReLU' applied on the fly to the dOut operand (see PwArgs::pro_y): a_y [M,R,Kp], a_gamma [R], a_alpha [1],
+    // a_ms [M,2], a_part [M, a_nparts, 2] fp64; the workgroups of column tile 0 also emit the PReLU-slope gradient partials
+    // dalpha_part [nsplit * tiles_r] (a_y == NULL: plain dOut)
+    const float* a_y; const float* a_gamma; const float* a_alpha; const float* a_ms; const double* a_part; int a_nparts;
+    float* dalpha_part;
 };
 
 

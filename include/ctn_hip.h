@@ -110,6 +110,22 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
                             const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
                             void* stream);
 
+/* b3 arithmetic: the backward pass of "gLN(PReLU(y))" (ctn_gln_prelu_bwd below) folded into its two consumers, so that the
+ * gradient with respect to the norm's OUTPUT (dN) is their operand and the input gradient dY is never written:
+ *   dY = rstd*(gamma*dN - S1/n - xh*S2/n) * prelu'(y),  xh = (prelu(y,alpha) - mean)*rstd,  (mean, rstd) = ms [M,2],
+ *   (S1, S2) = sums of the [M, nparts, 2] fp64 partials sums_part, n = channels*K  (src/conv_tasnet.py:224-225,338-361 backward).
+ * ctn_pw_gemm_glnbwd:  Out[m] = Wp . dY[m] + residual[m]   (Wp: pieces of the [R, Cn] operand from ctn_split_b3_batch; dN, y: [M,Cn,Kp]).
+ * ctn_pw_wgrad_glnbwd: dW[R,Cn] = sum_{m,k} dY[m,r,k] * X[m,c,k]  (dN, y: [M,R,Kp]) and the PReLU-slope gradient as
+ *   ctn_pw_wgrad_glnbwd_parts(M,R,Cn,Kp) partial sums dalpha_part (add them in order; ctn_dw_bwd_finalize does).
+ * dY is bit for bit what ctn_gln_prelu_bwd writes, so Out and dW equal the unfused sequence bitwise. */
+int ctn_pw_gemm_glnbwd(const void* Wp, const float* dN, const float* y, float* Out, int M, int R, int Cn, int K, int Kp,
+                       const double* sums_part, int nparts, const float* gamma, const float* alpha, const float* ms,
+                       const float* residual, void* stream);
+int ctn_pw_wgrad_glnbwd(const float* dN, const float* y, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                        const double* sums_part, int nparts, const float* gamma, const float* alpha, const float* ms,
+                        float* dalpha_part, void* workspace, size_t workspace_bytes, void* stream);
+int ctn_pw_wgrad_glnbwd_parts(int M, int R, int Cn, int Kp);
+
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
  * PReLU (:224,:259) and GlobalLayerNorm (:225,:260,:338-361) on either side fused in. */

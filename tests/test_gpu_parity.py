@@ -966,3 +966,55 @@ def test_encoder_kernel_matches_conv1d(L, N, T, M):
     assert float(w[..., K:].abs().max()) == 0.0
     with pytest.raises(ctn.CtnError):
         ctn.lib.call("ctn_encoder_fwd", ops._p(mix_d), ops._p(U_d), ops._p(w), M, T, N, 24, K, Kp, ops._stream())
+
+
+def test_gln_backward_folded_into_its_consumers():
+    """ctn_pw_gemm_glnbwd / ctn_pw_wgrad_glnbwd (b3): the gLN'/PReLU' backward pass applied in the operand prologues of the
+    input-gradient GEMM and of the weight gradient, against ctn_gln_prelu_bwd followed by the plain forms -- bitwise for the
+    tensors, fp32 round-off for the PReLU-slope gradient (another fixed summation order) -- and against fp64 torch."""
+    if ARITH["name"] != "b3":
+        pytest.skip("b3 kernels")
+    M, B, H, K = 3, 72, 136, 1203
+    Kp = ops.padded_frames(K)
+    dn = pad(torch.randn(M, H, K, generator=g(51)), Kp).to(DEV)
+    y = pad(torch.randn(M, H, K, generator=g(52)), Kp).to(DEV)
+    x = pad(torch.randn(M, B, K, generator=g(53)), Kp).to(DEV)
+    res = pad(torch.randn(M, B, K, generator=g(54)), Kp).to(DEV)
+    w1 = (torch.randn(H, B, generator=g(55)) * 0.2).to(DEV)
+    gam = torch.randn(1, H, 1, generator=g(56)).to(DEV)
+    al = torch.tensor([0.3], device=DEV)
+    ms = torch.tensor([[0.1, 1.3], [-0.2, 0.7], [0.05, 1.1]], device=DEV)
+    # sums partials [M, H, 2] as dw_bwd emits them: S1 = sum gamma*dn, S2 = sum gamma*dn*xh per (utterance, channel)
+    pre = torch.where(y >= 0, y, al * y)
+    xh = (pre - ms[:, 0].view(-1, 1, 1)) * ms[:, 1].view(-1, 1, 1)
+    t = gam * dn
+    part = torch.stack([t[..., :K].double().sum(-1), (t * xh)[..., :K].double().sum(-1)], -1).contiguous()
+    # unfused: B4 in place, then the plain GEMMs
+    dh1 = torch.empty_like(dn)
+    dap = torch.empty(M * H, device=DEV)
+    ctn.lib.call("ctn_gln_prelu_bwd", ops._p(dn), ops._p(y), ops._p(dh1), M, H, K, Kp, ops._p(gam), ops._p(al), ops._p(ms),
+                 ops._p(part), H, ops._p(dap), ops._stream())
+    pieces = ops._b3_pieces(w1, B, H, True)                   # operand [R = B, Cn = H] of dx = W1^T . dh1
+    dx_ref = _raw_pw_gemm(pieces, dh1, B, H, K, 2, res)
+    dW_ref = ops.pw_wgrad(dh1, x, H, B, K)
+    # fused
+    dx = torch.empty((M, B, Kp), device=DEV)
+    ctn.lib.call("ctn_pw_gemm_glnbwd", ops._p(pieces), ops._p(dn), ops._p(y), ops._p(dx), M, B, H, K, Kp, ops._p(part), H, ops._p(gam),
+                 ops._p(al), ops._p(ms), ops._p(res), ops._stream())
+    nparts = ctn.lib.ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp)
+    dap2 = torch.empty(nparts, device=DEV)
+    dW = torch.empty((H, B), device=DEV)
+    nbytes = ctn.lib.ctn_pw_wgrad_workspace(M, H, B, Kp)
+    wsb = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    ctn.lib.call("ctn_pw_wgrad_glnbwd", ops._p(dn), ops._p(y), ops._p(x), ops._p(dW), M, H, B, K, Kp, ops._p(part), H, ops._p(gam), ops._p(al),
+                 ops._p(ms), ops._p(dap2), ops._p(wsb), nbytes, ops._stream())
+    assert torch.equal(dx, dx_ref) and torch.equal(dW, dW_ref)
+    assert abs(float(dap2.sum()) - float(dap.sum())) <= 2e-5 * float(dap.abs().sum())
+    # and fp64: dY = rstd*(gamma*dn - S1/n - xh*S2/n) * prelu'(y) over frames < K
+    n = H * K
+    S1, S2 = part[..., 0].sum(1).view(-1, 1, 1), part[..., 1].sum(1).view(-1, 1, 1)
+    dy = ms[:, 1].view(-1, 1, 1).double() * (t.double() - S1 / n - xh.double() * S2 / n) * torch.where(y >= 0, 1.0, 0.3).double()
+    dy[..., K:] = 0
+    ref = torch.einsum("cr,mck->mrk", w1.double(), dy) + res.double()
+    assert rel_err(dx[..., :K], ref[..., :K]) < 5e-6
+    assert rel_err(dW, torch.einsum("mrk,mck->rc", dy, x.double())) < 5e-6
