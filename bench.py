@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--arith", choices=["b3", "fp32"], default=os.environ.get("CTN_GEMM_ARITH", "b3"),
                     help="GEMM arithmetic: b3 = two bf16 pieces per fp32 operand on the bf16 matrix cores (library default), "
                          "fp32 = fp32-MFMA kernels")
+    ap.add_argument("--no-fp32-reference", action="store_true", help="skip the short fp32-arithmetic run after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CTN_BENCH_GRAPH", "0")),
@@ -359,6 +360,34 @@ def main():
             "model_tflops": round(value * ftrain / 1e12, 2),
             "model_frac_of_f32_mfma_peak": round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }
+    if args.arith == "b3" and graphed is None and not args.no_fp32_reference:
+        # the same workload on the bit-exact fp32-MFMA kernels, timed the same way right after the main measurement (every rank
+        # takes part): `value` is the b3 number -- products from two bf16 pieces per operand, parity within the 1e-3 dB budget
+        # (tests/) -- and this record shows what the exact-fp32 products cost on the same box in the same process
+        ctn.set_gemm_arith("fp32")
+        nref = max(3, min(args.steps, 10))
+        for _ in range(2):
+            step()
+        loss_acc.zero_()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nref):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dref = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dref], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dref = float(t)
+        ctn.set_gemm_arith("b3")
+        if rank == 0:
+            out["fp32_arithmetic"] = {"value": round(PER_GPU_BATCH * world * nref / dref, 2), "unit": "utterances/sec",
+                                      "ms_per_step": round(1e3 * dref / nref, 3), "steps": nref, "warmup": 2,
+                                      "note": "same step with CTN_GEMM_ARITH=fp32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 products)"}
     if not args.no_roofline and graphed is None:
         # every rank takes part (the steps contain the gradient all-reduce); rank 0 keeps the table
         probe_steps, was = 3, ops._COMPOSITE
