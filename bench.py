@@ -185,7 +185,7 @@ def _gemm_bytes(name, a, K):
     return t * (R + Cn)                                           # weight gradient: both activations
 
 
-def family_table(probe, cfg, K, steps):
+def family_table(probe, stack, cfg, K, steps):
     """Per kernel family: launches, in-step time, and the roofline that binds it.  A GEMM family is priced against BOTH
     roofs -- executed MFMA FLOPs (3 bf16 MFMAs per algorithmic product step under b3, 1 fp32 MFMA under fp32) over the
     dense peak of that MFMA type, and algorithmic bytes over 8 TB/s -- and reports the binding (larger) bound."""
@@ -194,7 +194,39 @@ def family_table(probe, cfg, K, steps):
     hbm_bytes = {"ctn_dw_fwd": 2, "ctn_dw_bwd": 4, "ctn_gln_prelu_bwd": 3}      # tensors of M*H*K*4 bytes read + written
     b3 = ARITH["name"] == "b3"
     fams = {}
+    B = c["B"]
+    gln = cfg["norm_type"] == "gLN"
+    # launch groups of the composite stacks (ctn_probe_read): family id -> (name, GEMM shape (M, R, Cn) or None, tensors of
+    # M*ch*K*4 bytes moved as (channels, count) pairs)
+    t4 = 4.0 * M * K
+    STACK = {
+        0: ("K1 1x1 B->H (+ PReLU/gLN statistics)" if gln else "K1 1x1 B->H", (M, H, B), t4 * (B + H)),
+        1: ("K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)" if gln else "K2 dw_fwd (depthwise)", None, t4 * 2 * H),
+        2: ("K3 1x1 H->B (gLN prologue + residual)" if gln else "K3 1x1 H->B + residual", (M, B, H), t4 * (H + 2 * B)),
+        3: ("B1 input gradient W2^T.dout (+ gLN backward sums)" if gln else "B1 input gradient W2^T.dout", (M, H, B), t4 * (B + (2 if gln else 1) * H)),
+        4: ("B2 weight gradient dW2 (gLN prologue) + slab_reduce" if gln else "B2 weight gradient dW2 + slab_reduce", (M, B, H), t4 * (B + H)),
+        5: ("B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)" if gln else "B3 dw_bwd (depthwise^T)", None, t4 * (4 if gln else 3) * H),
+        6: ("B4 gln_prelu_bwd", None, t4 * 3 * H),
+        7: ("B5 input gradient W1^T.dh1 + dout", (M, B, H), t4 * (H + 2 * B)),
+        8: ("B6 weight gradient dW1 + slab_reduce", (M, H, B), t4 * (B + H)),
+        9: ("fixed-order parameter-gradient sums (finalize)", None, 0.0),
+        10: ("weight operands of the stack (bf16 pieces / transposes), 2 launches per direction", None, 0.0),
+        11: ("cln_fwd (channel-wise LayerNorm of PReLU(.))", None, t4 * 2 * H),
+        12: ("cln_bwd (input gradient + parameter-gradient partials)", None, t4 * 3 * H),
+        13: ("dw_bwd_taps (depthwise weight gradient sums)", None, 0.0),
+    }
+    for fid, us in stack:
+        name, shape, nbytes = STACK[fid]
+        f = fams.setdefault(name, {"bound": "mfma" if shape else "hbm", "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": "stack"})
+        f["us"].append(us)
+        f["bytes"] += nbytes
+        if shape:
+            f["flops"] += 2.0 * shape[1] * shape[2] * K * shape[0]
+            small = (shape[1] < 32 or shape[2] < 32) if fid in (4, 8) else shape[1] < 64
+            f["b3"] += int(b3 and not small)
     for name, a, e0, e1 in probe:
+        if name.startswith("ctn_tcn_") or name.startswith("ctn_probe"):
+            continue                                # the stacks as wholes: their launch groups are in `stack`
         fam, bound, shape = _family(name, a)
         f = fams.setdefault(fam, {"bound": bound, "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": name})
         f["us"].append(1e3 * e0.elapsed_time(e1))
@@ -253,9 +285,11 @@ def roofline(rows, probe_steps):
             "peak": dom.get("peak"), "unit": dom.get("unit"),
             "frac": dom.get("frac"), "us_per_launch": dom["us_per_launch"], "launches_per_step": dom["launches_per_step"],
             "work_per_launch": dom.get("work_per_launch"), "traffic": traffic, "traffic_source": src,
-            "how": "largest total time among the kernel families of %d extra training steps after the timed region, each "
-                   "launch group bracketed by a HIP-event pair on the stream it is launched on (weight-gradient groups run "
-                   "on the second stream and overlap the chain, so in-step durations include that sharing)" % probe_steps,
+            "how": "largest total time among the kernel families of %d extra training steps after the timed region, run "
+                   "exactly like the timed steps (composite stacks, second stream); every launch group is bracketed by a "
+                   "HIP-event pair on the stream it is launched to -- inside the library for the stacks (ctn_probe_enable), "
+                   "in the Python wrapper for the other calls (weight-gradient groups run on the second stream and overlap "
+                   "the chain, so in-step durations include that sharing)" % probe_steps,
             "families": rows}
 
 
@@ -389,19 +423,26 @@ def main():
                                       "ms_per_step": round(1e3 * dref / nref, 3), "steps": nref, "warmup": 2,
                                       "note": "same step with CTN_GEMM_ARITH=fp32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 products)"}
     if not args.no_roofline and graphed is None:
-        # every rank takes part (the steps contain the gradient all-reduce); rank 0 keeps the table
-        probe_steps, was = 3, ops._COMPOSITE
-        ops._COMPOSITE = False                  # per-kernel entry points: the same kernels, individually bracketed
-        step()                                  # settle allocations of the per-kernel path
+        # every rank takes part (the steps contain the gradient all-reduce); rank 0 keeps the table.  The steps run exactly as
+        # in the timed region (composite stacks, second stream): the library brackets every launch group of the stacks with a
+        # HIP-event pair on its stream (ctn_probe_enable), lib.probe does the same for the calls made from Python (front end,
+        # back end, loss, optimiser)
+        import ctypes
+        probe_steps = 3
+        step()
         torch.cuda.synchronize()
         ctn.lib.probe = []
+        ctn.lib.call("ctn_probe_enable", 1)
         for _ in range(probe_steps):
             step()
         torch.cuda.synchronize()
+        cap = 4096 * probe_steps
+        fam_ids, fam_us = (ctypes.c_int * cap)(), (ctypes.c_float * cap)()
+        n = ctn.lib.load().ctn_probe_read(fam_ids, fam_us, cap)
         probe, ctn.lib.probe = ctn.lib.probe, None
-        ops._COMPOSITE = was
         if rank == 0:
-            out["roofline"] = roofline(family_table(probe, cfg, K, probe_steps), probe_steps)
+            stack = [(int(fam_ids[i]), float(fam_us[i])) for i in range(min(n, cap))]
+            out["roofline"] = roofline(family_table(probe, stack, cfg, K, probe_steps), probe_steps)
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

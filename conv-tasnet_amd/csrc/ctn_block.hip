@@ -20,6 +20,53 @@ int g_ctn_block_fuse_b4 = 0;             // ctn_tune("fuse_b4", 1): gln_prelu_bw
 int g_ctn_block_fin_side = 1;            // ctn_tune("fin_side", 0): parameter-gradient sums on the chain's stream (A/B runs)
 int g_ctn_block_wt = 1;                     // ctn_tune("block_wt", 0): forward GEMMs on the stored [O, I] weights (A/B runs)
 
+// ---- measurement hook (bench.py's roofline leg): HIP events around every launch group of the composite stacks, on the stream
+// the group is launched to.  Off by default (no events, no overhead); ctn_probe_enable(1) starts a recording, ctn_probe_read
+// waits for the recorded events, returns (family id, microseconds) per launch group in issue order and ends the recording.
+enum { F_K1 = 0, F_K2, F_K3, F_B1, F_B2, F_B3, F_B4, F_B5, F_B6, F_FIN, F_PREP, F_CLN_FWD, F_CLN_BWD, F_TAPS, F_COUNT };
+namespace {
+struct ProbeRec { int fam; hipEvent_t e0, e1; };
+std::vector<ProbeRec> g_probe;
+bool g_probe_on = false;
+struct ProbeMark {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st;
+    int fam;
+    ProbeMark(int f, void* stream) : st((hipStream_t)stream), fam(f) {
+        if (!g_probe_on) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+        hipEventRecord(e0, st);
+    }
+    ~ProbeMark() {
+        if (e0 == nullptr) return;
+        hipEventRecord(e1, st);
+        g_probe.push_back(ProbeRec{fam, e0, e1});
+    }
+};
+}  // namespace
+#define PROBED(fam, stream, expr) [&]() -> int { ProbeMark pm_(fam, stream); return (expr); }()
+
+extern "C" int ctn_probe_enable(int on) {
+    for (ProbeRec& r : g_probe) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_probe.clear();
+    g_probe_on = on != 0;
+    return CTN_OK;
+}
+
+extern "C" int ctn_probe_read(int* fam, float* us, int cap) {
+    int n = 0;
+    for (ProbeRec& r : g_probe) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+        if (n < cap && fam && us) { fam[n] = r.fam; us[n] = ms * 1e3f; }
+        ++n;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_probe.clear();
+    g_probe_on = false;
+    return n;
+}
+
 namespace {
 
 enum { P_W1 = 0, P_A1, P_G1, P_B1, P_D, P_A2, P_G2, P_B2, P_W2, NPARAM };
@@ -55,10 +102,10 @@ int prepare_weights(const void* const* params, int nblocks, int B, int H, bool b
         }
         int* const tw = half == 0 ? tw_h : tw_b;
         if (pieces(R)) {
-            if ((rc = ctn_split_b3_batch(src.data(), dst.data(), nblocks, R, Cn, backward ? 1 : 0, stream))) return rc;
+            if ((rc = PROBED(F_PREP, stream, ctn_split_b3_batch(src.data(), dst.data(), nblocks, R, Cn, backward ? 1 : 0, stream)))) return rc;
             *tw = 2;
         } else if (!backward) {
-            if ((rc = ctn_transpose_batch(src.data(), dst.data(), nblocks, R, Cn, stream))) return rc;     // [R, Cn] -> [Cn, R]
+            if ((rc = PROBED(F_PREP, stream, ctn_transpose_batch(src.data(), dst.data(), nblocks, R, Cn, stream)))) return rc;     // [R, Cn] -> [Cn, R]
             *tw = 1;
         } else {
             *tw = -1;       // use the stored matrix (trans_w = 1)
@@ -154,14 +201,14 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const ms1 = ms + ((size_t)(save ? i : 0) * 2 + 0) * M * 2;
         float* const ms2 = ms + ((size_t)(save ? i : 0) * 2 + 1) * M * 2;
-        int rc = ctn_pw_gemm(w1t, x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             p[P_A1], st1, 0, stream);
+        int rc = PROBED(F_K1, stream, ctn_pw_gemm(w1t, x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             p[P_A1], st1, 0, stream));
         if (rc) return rc;
-        rc = ctn_dw_fwd(h1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, st1, w.np1, p[P_G1], p[P_B1], p[P_A1], ms1,
-                        p[P_A2], st2, stream);
+        rc = PROBED(F_K2, stream, ctn_dw_fwd(h1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, st1, w.np1, p[P_G1], p[P_B1], p[P_A1], ms1,
+                        p[P_A2], st2, stream));
         if (rc) return rc;
-        rc = ctn_pw_gemm(w2t, d, out, M, B, H, K, Kp, tw2, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
-                         stream);
+        rc = PROBED(F_K3, stream, ctn_pw_gemm(w2t, d, out, M, B, H, K, Kp, tw2, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
+                         stream));
         if (rc) return rc;
         x = out;
     }
@@ -211,22 +258,22 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         float* const da1p = (float*)(ws + w.da1p + (size_t)i * w.da1p_slot);
         double* const s1p = (double*)(ws + w.s1p + (size_t)i * w.s1p_slot);
         // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
-        if (twh == 2) rc = ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
-        else rc = ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream);
+        if (twh == 2) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
+        else rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         if (rc) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        rc = ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst);
+        rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst));
         if (rc) return rc;
         // gLN2 <- PReLU2 <- depthwise <- gLN1 output in one pass, then gLN1 + PReLU1 backward in place
-        rc = ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
-                        p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream);
+        rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
+                        p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream));
         if (rc) return rc;
         // gLN1' / PReLU1' backward: its own pass (B4), or -- opt-in, b3 arithmetic -- folded into the prologues of its two
         // consumers (dn1 stays the raw gradient; the 157 MB pass and its launch leave the chain, the two GEMMs read h1 too)
         const bool fused = g_ctn_block_fuse_b4 && twb == 2 && ctn_gemm_arith() == 1 && H >= 32 && B >= 32;
         int n_da1 = M * H;
         if (!fused) {
-            rc = ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream);
+            rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream));
             if (rc) return rc;
         } else {
             n_da1 = ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp);
@@ -235,21 +282,21 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         // optimiser: second stream
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         auto wgrad1 = [&]() -> int {
-            if (fused) return ctn_pw_wgrad_glnbwd(dn1, h1, x, g[P_W1], M, H, B, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, da1p, slab, w.slab_bytes, wst);
-            return ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst);
+            if (fused) return PROBED(F_B6, wst, ctn_pw_wgrad_glnbwd(dn1, h1, x, g[P_W1], M, H, B, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, da1p, slab, w.slab_bytes, wst));
+            return PROBED(F_B6, wst, ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
         };
         auto finalize = [&](void* st) -> int {
-            return ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st);
+            return PROBED(F_FIN, st, ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st));
         };
         if (side_stream) {          // (the fused weight gradient produces the PReLU-slope partials: finalize after it)
             if ((rc = wgrad1())) return rc;
             if ((rc = finalize(g_ctn_block_fin_side || fused ? wst : stream))) return rc;
         }
         if (fused)
-            rc = ctn_pw_gemm_glnbwd(wreg + (size_t)(2 * i + 1) * slot, dn1, h1, dx, M, B, H, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, dy, stream);
+            rc = PROBED(F_B5, stream, ctn_pw_gemm_glnbwd(wreg + (size_t)(2 * i + 1) * slot, dn1, h1, dx, M, B, H, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, dy, stream));
         else
-            rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
-                             nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream);
+            rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                             nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
         if (rc) return rc;
         if (!side_stream) {
             if ((rc = wgrad1())) return rc;
@@ -323,14 +370,14 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
         float* const h1 = h1s + s * hsz; float* const n1 = n1s + s * hsz; float* const d = ds + s * hsz; float* const n2 = n2s + s * hsz;
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const stb = st + s * 4 * ssz;
-        if ((rc = ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i) * slot), x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, 0, stream))) return rc;
-        if ((rc = ctn_cln_fwd(h1, n1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], stream))) return rc;
-        if ((rc = ctn_dw_fwd(n1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, stream))) return rc;
-        if ((rc = ctn_cln_fwd(d, n2, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], stream))) return rc;
-        if ((rc = ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i + 1) * slot), n2, out, M, B, H, K, Kp, tw2, nullptr, 0, nullptr, nullptr,
-                              nullptr, nullptr, x, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = PROBED(F_K1, stream, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i) * slot), x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, 0, stream)))) return rc;
+        if ((rc = PROBED(F_CLN_FWD, stream, ctn_cln_fwd(h1, n1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], stream)))) return rc;
+        if ((rc = PROBED(F_K2, stream, ctn_dw_fwd(n1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, stream)))) return rc;
+        if ((rc = PROBED(F_CLN_FWD, stream, ctn_cln_fwd(d, n2, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], stream)))) return rc;
+        if ((rc = PROBED(F_K3, stream, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i + 1) * slot), n2, out, M, B, H, K, Kp, tw2, nullptr, 0, nullptr, nullptr,
+                              nullptr, nullptr, x, nullptr, nullptr, 0, stream)))) return rc;
         x = out;
     }
     return CTN_OK;
@@ -377,24 +424,24 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         float* const pcw = (float*)(ws + w.pcw + (size_t)i * w.pcw_slot);
         float* const pcn2 = (float*)(ws + w.pcn + (size_t)(2 * i) * w.pcn_slot), * const pcn1 = (float*)(ws + w.pcn + (size_t)(2 * i + 1) * w.pcn_slot);
         float* const dap2 = (float*)(ws + w.dap + (size_t)(2 * i) * w.dap_slot), * const dap1 = (float*)(ws + w.dap + (size_t)(2 * i + 1) * w.dap_slot);
-        if ((rc = ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
-                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = PROBED(F_B1, stream, ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream)))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        if ((rc = ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
-        if ((rc = ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, stream))) return rc;
-        if ((rc = ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream))) return rc;
-        if ((rc = ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, stream))) return rc;
+        if ((rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
+        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, stream)))) return rc;
+        if ((rc = PROBED(F_B3, stream, ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream)))) return rc;
+        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, stream)))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         // the three fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
         void* const fst = g_ctn_block_fin_side ? wst : stream;
-        if ((rc = ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst))) return rc;
-        if ((rc = ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst))) return rc;
-        if ((rc = ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst))) return rc;
-        if (side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
-        if ((rc = ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
-                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream))) return rc;
-        if (!side_stream && (rc = ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst))) return rc;
+        if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
+        if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
+        if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst)))) return rc;
+        if (side_stream && (rc = PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
+        if ((rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream)))) return rc;
+        if (!side_stream && (rc = PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
     }
     if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;
     return CTN_OK;

@@ -206,6 +206,14 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks);
 
+/* Measurement hook for the composite stacks (bench.py's roofline leg): ctn_probe_enable(1) makes every launch group issued
+ * by ctn_tcn_*_fwd / _bwd on this thread's process record a HIP-event pair on the stream it is launched to;
+ * ctn_probe_read waits for them, fills fam[i] (0..13: K1 K2 K3 B1 B2 B3 B4 B5 B6 finalize weight-prep cln_fwd cln_bwd taps)
+ * and us[i] (microseconds) in issue order for up to cap groups, returns the number recorded and ends the recording.
+ * Off by default: no events, no overhead. */
+int ctn_probe_enable(int on);
+int ctn_probe_read(int* fam, float* us, int cap);
+
 /* The same for a stack of cLN TemporalBlocks (norm_type = 'cLN': the causal BASELINE config), un-fused norms: per block
  * forward  1x1 -> cLN(PReLU) -> depthwise -> cLN(PReLU) -> 1x1 + residual,  backward the adjoint chain with the two weight
  * gradients on side_stream.  Saved by forward (slot per block): xs [nblocks][M,B,Kp]; h1s, n1s, ds, n2s [nblocks][M,H,Kp]
