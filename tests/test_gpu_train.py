@@ -323,3 +323,30 @@ def test_direct_gradients_refuse_silent_overwrite_and_are_readable_after_backwar
     backprop()                                  # fine again after zero_grad()
     torch.cuda.synchronize()
     assert torch.equal(g1, opt.flat_grads)
+
+
+def test_library_probe_brackets_every_launch_group_of_the_stacks():
+    """ctn_probe_enable / ctn_probe_read (bench.py's roofline leg): one record per launch group of the composite stacks in
+    issue order, family ids in range, positive durations; reading ends the recording."""
+    import ctypes
+    from conv_tasnet_amd import ops
+    if not ops._COMPOSITE:
+        pytest.skip("per-kernel sequencing selected")
+    torch.manual_seed(0)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 3, 2, 2).to(DEV)          # 6 gLN blocks
+    mix, lens, src = O.synth_batch(5, 2, 4000)
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    opt.zero_grad()
+    ctn.lib.call("ctn_probe_enable", 1)
+    ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0].backward()
+    torch.cuda.synchronize()
+    fam, us = (ctypes.c_int * 512)(), (ctypes.c_float * 512)()
+    n = ctn.lib.load().ctn_probe_read(fam, us, 512)
+    # per block: K1 K2 K3 forward; B1 B2 B3 B4 B5 B6 finalize backward; plus the weight preparation launches
+    ids = [fam[i] for i in range(n)]
+    assert n >= 6 * 10 and all(0 <= f <= 13 for f in ids) and all(us[i] > 0 for i in range(n))
+    for f in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+        assert ids.count(f) == 6, (f, ids.count(f))
+    assert ctn.lib.load().ctn_probe_read(fam, us, 512) == 0         # recording ended
+    m(mix.to(DEV))
+    assert ctn.lib.load().ctn_probe_read(fam, us, 512) == 0         # and off
