@@ -17,7 +17,7 @@ PY
 export TMPDIR=/tmp
 R=$(pwd)
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench_final -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_bench_final.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench_final -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-fp32-reference > $R/gpurun_out/prof_bench_final.log 2>&1
 cd $R
 head -8 gpurun_out/prof_bench_final/p_kernel_stats.csv | cut -c1-150
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
