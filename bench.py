@@ -33,7 +33,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
                                # benchmarks/mfma_probe.hip, profiles/r02_a_mfma_probe.txt)
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0          # same guide, HBM3E peak
-ARITH = {"name": "b3"}         # GEMM arithmetic of this run (--arith): "b3" = 3 bf16 MFMAs per product step, "fp32" = fp32 MFMA
+ARITH = {"name": "b6"}         # GEMM arithmetic of this run (--arith): "b6" = 6 bf16 MFMAs per product step (three bf16 pieces per
+                               # fp32 operand: fp32-faithful products, the library default), "fp32" = fp32 MFMA, "b3" = 3 bf16 MFMAs
+                               # (two pieces: ~16-bit products, opt-in, NOT reference precision)
+ARITH_IDS = {"fp32": 0, "b3": 1, "b6": 2}
+MFMA_PER_STEP = {"b3": 3, "b6": 6}
 PER_GPU_BATCH = 8
 CONFIGS = {
     "paper": dict(model=dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2), norm_type="gLN", causal=False, T=32000, sr=8000,
@@ -97,16 +101,18 @@ def _host_cpu():
     return model, max(n, 1), ", ".join("%s=%d" % kv for kv in limits.items())
 
 
-def cpu_baseline(cfg, budget_s=40.0):
+def cpu_baseline(cfg, budget_s=150.0):
     """The oracle (torch CPU restatement of the reference step: fwd + loss + bwd + clip(5) + Adam) on this host, batch 8,
-    all physical cores this process may use; then the same on 8 threads (the survey container's count).  Bounded in wall
-    time, not in sample: up to 3 warm-up + 10 timed steps inside the budget (a step of the paper config takes seconds)."""
+    all physical cores this process may use; then the same on 8 threads (the survey container's count).  BASELINE.md section 4
+    asks for warm-up + >= 10 timed steps, median and min; a paper-config step takes ~20 s on a 1-GPU box's 16-core share, so the
+    sample is bounded: the first call is a warm-up (more while steps are short), then timed steps until 10 are in, or until at
+    least 5 (3 when a step exceeds 25 s) are in and the wall budget is spent."""
     from oracle import ctn_oracle as O
     ocfg = O.Config(norm_type=cfg["norm_type"], causal=cfg["causal"], **cfg["model"])
     model, cores, how = _host_cpu()
     mix, lens, src = O.synth_batch(0, PER_GPU_BATCH, cfg["T"], C=cfg["model"]["C"], sr=cfg["sr"])
 
-    def run(threads, budget, max_warm, max_steps):
+    def run(threads, budget, max_warm, min_steps, max_steps):
         torch.set_num_threads(threads)
         sd, state = O.init_params(ocfg, seed=0), {}
         t_start, times, warm = time.perf_counter(), [], 0
@@ -115,14 +121,15 @@ def cpu_baseline(cfg, budget_s=40.0):
             O.train_step(ocfg, sd, state, mix, src, lens)
             dt = time.perf_counter() - t0
             elapsed = time.perf_counter() - t_start
-            if warm < max_warm and (warm == 0 or elapsed + 2 * dt < budget * 0.35):
+            if warm < max_warm and (warm == 0 or dt < 2.0):
                 warm += 1                      # the first call always is a warm-up (allocator, thread pool)
-            else:
-                times.append(dt)
-            if len(times) >= max_steps or (times and elapsed + dt > budget):
+                continue
+            times.append(dt)
+            need = min_steps if dt <= 25.0 else min(min_steps, 3)
+            if len(times) >= max_steps or (len(times) >= need and elapsed + dt > budget):
                 return warm, times
 
-    warm, times = run(cores, budget_s, 3, 10)
+    warm, times = run(cores, budget_s, 3, 5, 10)
     med, best = statistics.median(times), min(times)
     out = {"value": round(PER_GPU_BATCH / med, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
            "cpu_model": model, "cores_from": how, "batch": PER_GPU_BATCH, "warmup_steps": warm, "timed_steps": len(times),
@@ -134,9 +141,9 @@ def cpu_baseline(cfg, budget_s=40.0):
                      "value = batch / median step time"
                      % (len(times), PER_GPU_BATCH, warm, cores, budget_s)}
     if cores != 8:
-        w8, t8 = run(min(8, cores), budget_s * 0.4, 1, 3)
+        w8, t8 = run(min(8, cores), budget_s * 0.3, 1, 2, 3)
         out["threads8"] = {"value": round(PER_GPU_BATCH / statistics.median(t8), 4), "timed_steps": len(t8), "warmup_steps": w8,
-                           "threads": min(8, cores)}
+                           "threads": min(8, cores), "min_s_per_step": round(min(t8), 3)}
     return out
 
 
@@ -192,7 +199,8 @@ def family_table(probe, stack, cfg, K, steps):
     c = cfg["model"]
     M, H = PER_GPU_BATCH, c["H"]
     hbm_bytes = {"ctn_dw_fwd": 2, "ctn_dw_bwd": 4, "ctn_gln_prelu_bwd": 3}      # tensors of M*H*K*4 bytes read + written
-    b3 = ARITH["name"] == "b3"
+    b3 = ARITH["name"] in MFMA_PER_STEP          # split-bf16 arithmetic: the 1x1 GEMMs run on the bf16 matrix cores
+    nprod = MFMA_PER_STEP.get(ARITH["name"], 1)
     fams = {}
     B = c["B"]
     gln = cfg["norm_type"] == "gLN"
@@ -242,13 +250,17 @@ def family_table(probe, stack, cfg, K, steps):
         tot = sum(f["us"])
         n = len(f["us"])
         row = {"family": fam, "bound": f["bound"], "launches_per_step": round(n / steps, 1),
-               "us_per_launch": round(tot / n, 2), "ms_per_step": round(tot / steps / 1e3, 3)}
+               "us_per_launch": round(tot / n, 2), "ms_per_step": round(tot / steps / 1e3, 3),
+               "algorithmic_bytes_per_step": f["bytes"] / steps}
+        if f["flops"] > 0:
+            row["executed_mfma_flops_per_step"] = f["flops"] / steps * (nprod if f["b3"] * 2 > n else 1)
+            row["on_bf16_mfma"] = f["b3"] * 2 > n
         if f["flops"] > 0:
             on_b3 = f["b3"] * 2 > n
             peak = PEAK_BF16_MFMA_TFLOPS if on_b3 else PEAK_F32_MFMA_TFLOPS
-            mfma_flops = f["flops"] * (3 if on_b3 else 1)                    # executed MFMA FLOPs
+            mfma_flops = f["flops"] * (nprod if on_b3 else 1)                # executed MFMA FLOPs
             t_mfma, t_hbm = mfma_flops / (peak * 1e12), f["bytes"] / (PEAK_HBM_GBS * 1e9)
-            row["arith"] = "b3 (3 x v_mfma_f32_32x32x16_bf16 per 16-deep step)" if on_b3 else "fp32 (v_mfma_f32_32x32x2_f32)"
+            row["arith"] = ("%s (%d x v_mfma_f32_32x32x16_bf16 per 16-deep step)" % (ARITH["name"], nprod)) if on_b3 else "fp32 (v_mfma_f32_32x32x2_f32)"
             row["algorithmic_tflops"] = round(f["flops"] / (tot * 1e-6) / 1e12, 2)
             row["mfma_floor_us"] = round(t_mfma / n * 1e6, 2)
             row["hbm_floor_us"] = round(t_hbm / n * 1e6, 2)
@@ -269,11 +281,25 @@ def family_table(probe, stack, cfg, K, steps):
     return rows
 
 
-def roofline(rows, probe_steps):
+def roofline(rows, probe_steps, ms_per_step, fused_min_bytes):
     dom = rows[0]
+    # concurrency-neutral roll-up of the whole step: every family's algorithmic bytes (each operand / result tensor of each
+    # launch once -- this build's blocking) and executed MFMA FLOPs, over the TIMED step (not the sum of in-step durations,
+    # which double-counts the overlap of the two streams)
+    step_bytes = sum(r["algorithmic_bytes_per_step"] for r in rows)
+    bf16_flops = sum(r.get("executed_mfma_flops_per_step", 0.0) for r in rows if r.get("on_bf16_mfma"))
+    f32_flops = sum(r.get("executed_mfma_flops_per_step", 0.0) for r in rows if r.get("on_bf16_mfma") is False)
+    t = ms_per_step * 1e-3
+    step = {"ms_per_step": ms_per_step,
+            "algorithmic_bytes": step_bytes, "hbm_frac": round(step_bytes / t / (PEAK_HBM_GBS * 1e9), 4),
+            "fused_minimum_bytes": fused_min_bytes, "hbm_frac_of_fused_minimum": round(fused_min_bytes / t / (PEAK_HBM_GBS * 1e9), 4),
+            "executed_bf16_mfma_flops": bf16_flops, "bf16_mfma_frac": round(bf16_flops / t / (PEAK_BF16_MFMA_TFLOPS * 1e12), 4),
+            "executed_f32_mfma_flops": f32_flops, "f32_mfma_frac": round(f32_flops / t / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+            "note": "whole-step fractions: bytes (this build's blocking / SURVEY 8d's fused minimum 4K(3B+4H)+4K(3B+9H) per block "
+                    "and utterance) and executed MFMA FLOPs of one step over the timed ms_per_step and the peaks"}
     traffic, src = None, None
     for pmc in sorted(os.listdir(os.path.join(ROOT, "profiles"))):      # PMC passes (benchmarks/pmc_traffic.sh): family + arithmetic must match
-        if not (pmc.startswith("r02_pmc_") and pmc.endswith(".json")):
+        if not (pmc.startswith("r03_pmc_") and pmc.endswith(".json")):
             continue
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", pmc)))
@@ -281,7 +307,7 @@ def roofline(rows, probe_steps):
                 traffic, src = j.get("hbm_bytes_per_launch"), "profiles/" + pmc
         except Exception:
             pass
-    return {"bound": dom["bound"], "kernel": dom["family"], "achieved": dom.get("achieved"),
+    return {"step": step, "bound": dom["bound"], "kernel": dom["family"], "achieved": dom.get("achieved"),
             "peak": dom.get("peak"), "unit": dom.get("unit"),
             "frac": dom.get("frac"), "us_per_launch": dom["us_per_launch"], "launches_per_step": dom["launches_per_step"],
             "work_per_launch": dom.get("work_per_launch"), "traffic": traffic, "traffic_source": src,
@@ -299,10 +325,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="paper")
-    ap.add_argument("--arith", choices=["b3", "fp32"], default=os.environ.get("CTN_GEMM_ARITH", "b3"),
-                    help="GEMM arithmetic: b3 = two bf16 pieces per fp32 operand on the bf16 matrix cores (library default), "
-                         "fp32 = fp32-MFMA kernels")
-    ap.add_argument("--no-fp32-reference", action="store_true", help="skip the short fp32-arithmetic run after the timed region")
+    ap.add_argument("--arith", choices=["b6", "fp32", "b3"], default=os.environ.get("CTN_GEMM_ARITH", "b6"),
+                    help="GEMM arithmetic: b6 = three bf16 pieces per fp32 operand, six bf16 MFMAs per product step (fp32-faithful "
+                         "products; library default), fp32 = fp32-MFMA kernels, b3 = two pieces / three MFMAs (~16-bit products; "
+                         "NOT reference precision, opt-in)")
+    ap.add_argument("--no-side-arith", action="store_true", help="skip the short runs on the other arithmetics after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CTN_BENCH_GRAPH", "0")),
@@ -323,7 +350,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     ARITH["name"] = args.arith
-    ctn.lib.call("ctn_tune", b"arith", 1 if args.arith == "b3" else 0)
+    ctn.set_gemm_arith(args.arith)
     torch.manual_seed(0)
     model = ctn.ConvTasNet(**cfg["model"], norm_type=cfg["norm_type"], causal=cfg["causal"], mask_nonlinear="relu").to(device)
     opt = FlatAdam(model.parameters(), lr=1e-3)
@@ -382,7 +409,7 @@ def main():
             "metric": "4s 8kHz 2-spk utterances/sec (fwd+bwd)", "value": round(value, 2), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMM products from two bf16 pieces per operand, f32 accumulate)" if args.arith == "b3" else "f32",
+            "dtype": "f32 (GEMM products from two bf16 pieces per operand: ~16 significant bits, f32 accumulate)" if args.arith == "b3" else "f32",
             "gemm_arith": args.arith, "data": "synthetic",
             "config": {"workload": (cfg["name"] % PER_GPU_BATCH) + " utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam",
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": cfg["T"],
@@ -392,36 +419,48 @@ def main():
             # block on queue back-pressure, which is GPU time, not host work)
             "host_issue_ms_per_step": round(1e3 * statistics.median(issue[: max(3, len(issue) // 2)]), 3),
             "model_tflops": round(value * ftrain / 1e12, 2),
-            "model_frac_of_f32_mfma_peak": round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
         }
-    if args.arith == "b3" and graphed is None and not args.no_fp32_reference:
-        # the same workload on the bit-exact fp32-MFMA kernels, timed the same way right after the main measurement (every rank
-        # takes part): `value` is the b3 number -- products from two bf16 pieces per operand, parity within the 1e-3 dB budget
-        # (tests/) -- and this record shows what the exact-fp32 products cost on the same box in the same process
-        ctn.set_gemm_arith("fp32")
-        nref = max(3, min(args.steps, 10))
-        for _ in range(2):
-            step()
-        loss_acc.zero_()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(nref):
-            step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dref = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dref], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dref = float(t)
-        ctn.set_gemm_arith("b3")
+        if args.arith == "fp32":       # only a run ON the fp32 MFMA is priced against its peak
+            out["model_frac_of_f32_mfma_peak"] = round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)
+        else:                          # executed bf16-MFMA FLOPs of the whole step (nprod per algorithmic product) over the dense bf16 peak
+            out["executed_mfma_frac_of_bf16_peak"] = round(MFMA_PER_STEP[args.arith] * value * ftrain / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4)
+    if graphed is None and not args.no_side_arith:
+        # the same workload on the other arithmetics, timed the same way right after the main measurement (every rank takes
+        # part): `value` above is the run's own arithmetic; these side records show, on the same box in the same process, what
+        # the bit-exact fp32 MFMA costs and what the opt-in 16-bit-product b3 arithmetic would give
+        def side_run(name):
+            ctn.set_gemm_arith(name)
+            nref = max(3, min(args.steps, 10))
+            for _ in range(2):
+                step()
+            loss_acc.zero_()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nref):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dref = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dref], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dref = float(t)
+            ctn.set_gemm_arith(args.arith)
+            return {"value": round(PER_GPU_BATCH * world * nref / dref, 2), "unit": "utterances/sec",
+                    "ms_per_step": round(1e3 * dref / nref, 3), "steps": nref, "warmup": 2}
+        side = {}
+        for name, note in (("fp32", "same step with CTN_GEMM_ARITH=fp32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 products)"),
+                           ("b3", "same step with CTN_GEMM_ARITH=b3 (two bf16 pieces per operand, ~16-bit products: NOT reference "
+                                  "precision, opt-in; shown for comparison only)")):
+            if name != args.arith:
+                r = side_run(name)
+                r["note"] = note
+                side[name + "_arithmetic"] = r
         if rank == 0:
-            out["fp32_arithmetic"] = {"value": round(PER_GPU_BATCH * world * nref / dref, 2), "unit": "utterances/sec",
-                                      "ms_per_step": round(1e3 * dref / nref, 3), "steps": nref, "warmup": 2,
-                                      "note": "same step with CTN_GEMM_ARITH=fp32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 products)"}
+            out.update(side)
     if not args.no_roofline and graphed is None:
         # every rank takes part (the steps contain the gradient all-reduce); rank 0 keeps the table.  The steps run exactly as
         # in the timed region (composite stacks, second stream): the library brackets every launch group of the stacks with a
@@ -442,14 +481,18 @@ def main():
         probe, ctn.lib.probe = ctn.lib.probe, None
         if rank == 0:
             stack = [(int(fam_ids[i]), float(fam_us[i])) for i in range(min(n, cap))]
-            out["roofline"] = roofline(family_table(probe, stack, cfg, K, probe_steps), probe_steps)
+            c = cfg["model"]
+            fused_min = PER_GPU_BATCH * c["X"] * c["R"] * 4.0 * K * ((3 * c["B"] + 4 * c["H"]) + (3 * c["B"] + 9 * c["H"]))
+            out["roofline"] = roofline(family_table(probe, stack, cfg, K, probe_steps), probe_steps, out["ms_per_step"], fused_min)
+    # the process group is finished BEFORE the CPU leg: the other ranks must not sit in a collective (or hold the GPUs) while
+    # rank 0 spends minutes on the host cores
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

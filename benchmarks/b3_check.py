@@ -44,15 +44,15 @@ def timeit(fn, n=20):
 
 
 def report(name, fn, ref, scale):
-    arith(0)
-    o32 = fn()
-    t32 = timeit(fn)
-    arith(1)
-    o3 = fn()
-    t3 = timeit(fn)
-    e32 = ((o32.double() - ref).abs() / scale).max().item()
-    e3 = ((o3.double() - ref).abs() / scale).max().item()
-    print("%-26s fp32 %6.1f us err %.2e | b3 %6.1f us err %.2e" % (name, t32, e32, t3, e3), flush=True)
+    """max and rms error against fp64, in units of sum |a||b| (the natural scale of a dot product's rounding error)."""
+    line = "%-24s" % name
+    for v, tag in ((0, "fp32"), (2, "b6"), (1, "b3")):
+        arith(v)
+        o = fn()
+        t = timeit(fn)
+        e = (o.double() - ref).abs() / scale
+        line += " | %s %6.1f us max %.2e rms %.2e" % (tag, t, e.max().item(), e.pow(2).mean().sqrt().item())
+    print(line, flush=True)
 
 
 pre = torch.where(xH >= 0, xH, 0.25 * xH).double()
@@ -96,10 +96,10 @@ report("wgrad dW2 pro", lambda: ops.pw_wgrad(xB, xH, B, H, K, pro=(g, b, a, ms))
 from conv_tasnet_amd.ops import _p, _b3_pieces  # noqa: E402
 outH = torch.empty(M, H, Kp, device=dev)
 outB = torch.empty(M, B, Kp, device=dev)
-for tile in (1, 2, 0):      # 128x64, 256x64, 128x128: the kernels on pre-split weights (the composite's forms), GEMM alone
+for av, tile in [(a_, t_) for a_ in (2, 1) for t_ in (1, 2, 0)]:      # 128x64, 256x64, 128x128: the kernels on pre-split weights (the composite's forms), GEMM alone
     ctn.lib.call("ctn_tune", b"b3_tile", tile)
     ops._ws_cache.clear()
-    arith(1)
+    arith(av)
     p1, p2 = _b3_pieces(w1, H, B, False), _b3_pieces(w2, B, H, False)          # forward operands
     q2, q1 = _b3_pieces(w2, H, B, True), _b3_pieces(w1, B, H, True)            # input-gradient operands
     part = torch.empty((M, ctn.lib.ctn_pw_stats_parts(M, H, Kp), 2), dtype=torch.float64, device=dev)
@@ -108,5 +108,6 @@ for tile in (1, 2, 0):      # 128x64, 256x64, 128x128: the kernels on pre-split 
     k3 = lambda: ctn.lib.call("ctn_pw_gemm", _p(p2), _p(xH), _p(outB), M, B, H, K, Kp, 2, _p(st2), 1, _p(g), _p(b), _p(a), None, _p(xB), None, None, 0, sm)
     b1 = lambda: ctn.lib.call("ctn_pw_dgrad_gln_planes", _p(q2), _p(xB), _p(outH), M, H, B, K, Kp, _p(xH), _p(g), _p(a), _p(ms), _p(part), sm)
     b5 = lambda: ctn.lib.call("ctn_pw_gemm", _p(q1), _p(xH), _p(outB), M, B, H, K, Kp, 2, None, 0, None, None, None, None, _p(xB), None, None, 0, sm)
-    print("b3_tile=%d (pre-split weights)  K1 %6.1f  K3 %6.1f  B1 %6.1f  B5 %6.1f us" % (tile, timeit(k1), timeit(k3), timeit(b1), timeit(b5)), flush=True)
+    print(("b6" if av == 2 else "b3") + " b3_tile=%d (pre-split weights)  K1 %6.1f  K3 %6.1f  B1 %6.1f  B5 %6.1f us" % (tile, timeit(k1), timeit(k3), timeit(b1), timeit(b5)), flush=True)
 ctn.lib.call("ctn_tune", b"b3_tile", 1)
+arith(2)

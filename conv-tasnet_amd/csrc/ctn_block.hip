@@ -82,7 +82,7 @@ inline size_t wslot_bytes(int B, int H) {
     if (b > n) n = b;
     return align256(n);
 }
-inline bool pieces(int R) { return ctn_gemm_arith() == 1 && R >= 64; }      // the rule of ctn_pw_gemm(trans_w = 2)
+inline bool pieces(int R) { return ctn_gemm_arith() != 0 && R >= 64; }      // the rule of ctn_pw_gemm(trans_w = 2)
 
 // Weight operands of every block, prepared once per call into region [nblocks][2 slots]: slot 0 for the GEMM with H output
 // rows, slot 1 for the one with B output rows.  fwd: (w1 -> H rows, w2 -> B rows) as stored; bwd: (w2 -> H rows, w1 -> B rows)
@@ -143,7 +143,10 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.s1p = o; o += (size_t)nblocks * w.s1p_slot;
     // per-block slots: the finalize kernel of block i runs on the weight-gradient stream while the chain is already in block i-1
     w.pc_slot = align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
-    w.da1p_slot = align256((size_t)M * H * sizeof(float));
+    {   // PReLU-slope partials: M*H from ctn_gln_prelu_bwd, or one per (slab, row tile) from the fused weight gradient
+        const size_t n_unfused = (size_t)M * H, n_fused = (size_t)ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp);
+        w.da1p_slot = align256((n_unfused > n_fused ? n_unfused : n_fused) * sizeof(float));
+    }
     w.pc = o; o += (size_t)nblocks * w.pc_slot;
     w.da1p = o; o += (size_t)nblocks * w.da1p_slot;
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
@@ -270,7 +273,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         if (rc) return rc;
         // gLN1' / PReLU1' backward: its own pass (B4), or -- opt-in, b3 arithmetic -- folded into the prologues of its two
         // consumers (dn1 stays the raw gradient; the 157 MB pass and its launch leave the chain, the two GEMMs read h1 too)
-        const bool fused = g_ctn_block_fuse_b4 && twb == 2 && ctn_gemm_arith() == 1 && H >= 32 && B >= 32;
+        const bool fused = g_ctn_block_fuse_b4 && twb == 2 && ctn_gemm_arith() != 0 && H >= 32 && B >= 32;
         int n_da1 = M * H;
         if (!fused) {
             rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream));

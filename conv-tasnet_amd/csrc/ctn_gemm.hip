@@ -845,19 +845,21 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 int g_ctn_tile_override = -2;
 extern int g_ctn_block_wt, g_ctn_block_fin_side, g_ctn_block_fuse_b4;          // ctn_block.hip
 
-// GEMM arithmetic: 0 = fp32 MFMA (bit-exact fp32 FMA chains), 1 = "b3" (two bf16 pieces per operand, three bf16 MFMAs,
-// fp32 accumulation: ctn_gemm_b3.h).  CTN_GEMM_ARITH=fp32|b3, ctn_tune("arith", 0|1).  Layers with fewer than 64 output
-// rows (the decoder's basis GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
+// GEMM arithmetic (ctn_gemm_b3.h): 2 = "b6" (default: three bf16 pieces per operand, six bf16 MFMAs, fp32 accumulation --
+// fp32-faithful products), 1 = "b3" (two pieces, three MFMAs: ~16-bit products, opt-in), 0 = fp32 MFMA (bit-exact fp32 FMA
+// chains).  CTN_GEMM_ARITH=b6|b3|fp32, ctn_tune("arith", 2|1|0).  Layers with fewer than 64 output rows (the decoder's basis
+// GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
 static int g_arith = -1;
-static bool arith_b3() {
+static int arith_id() {
     if (g_arith < 0) {
         const char* e = getenv("CTN_GEMM_ARITH");
-        g_arith = (e && !strcmp(e, "fp32")) ? 0 : 1;
+        g_arith = (e && !strcmp(e, "fp32")) ? 0 : (e && !strcmp(e, "b3")) ? 1 : 2;
     }
-    return g_arith == 1;
+    return g_arith;
 }
-static bool b3_fwd(int R) { return arith_b3() && R >= 64; }
-static bool b3_wgrad(int R, int Cn) { return arith_b3() && R >= 32 && Cn >= 32; }
+static int arith_np() { return arith_id() == 0 ? 0 : arith_id() + 1; }       // pieces per operand (0: fp32 MFMA)
+static bool b3_fwd(int R) { return arith_id() != 0 && R >= 64; }
+static bool b3_wgrad(int R, int Cn) { return arith_id() != 0 && R >= 32 && Cn >= 32; }
 
 template <typename TL>
 static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd,
@@ -1013,7 +1015,7 @@ int ctn_tune_pw_tile(int id) {
 // internal (ctn_block.hip): 1 when the persistent kernels are active, i.e. fused prologue / statistics work with trans_w = 1
 int ctn_pw_uses_pk(void) { return use_pk() ? 1 : 0; }
 
-int ctn_gemm_arith(void) { return arith_b3() ? 1 : 0; }
+int ctn_gemm_arith(void) { return arith_id(); }
 
 int ctn_pw_stats_parts(int M, int R, int Kp) {
     if (b3_fwd(R)) {
@@ -1047,7 +1049,7 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
     a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
     CTN_REQUIRE(trans_w != 2 || b3_fwd(R), "ctn_pw_gemm: trans_w = 2 (pre-split weight pieces) needs the b3 arithmetic and R >= 64");
     if (b3_fwd(R)) {
-        ctn_b3_launch_fwd(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
+        ctn_b3_launch_fwd(arith_np(), a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
                           (hipStream_t)stream);
     } else if (use_pk()) {
         rc = launch_pk(a, trans_w, pro_part != nullptr, residual != nullptr, epi_part != nullptr, relu_out != 0, false,
@@ -1075,7 +1077,7 @@ static int dgrad_gln(const char* fn, const float* W, int planes, const float* dO
     a.W = W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
     if (b3_fwd(R)) {
-        ctn_b3_launch_fwd(a, planes ? 2 : 1, false, false, false, false, true, (hipStream_t)stream);
+        ctn_b3_launch_fwd(arith_np(), a, planes ? 2 : 1, false, false, false, false, true, (hipStream_t)stream);
     } else if (use_pk()) {
         rc = launch_pk(a, 1, false, false, false, false, true, (hipStream_t)stream);
         if (rc) return rc;
@@ -1099,14 +1101,15 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
     return dgrad_gln("ctn_pw_dgrad_gln_planes", (const float*)Wp, 1, dOut, dN, M, R, Cn, K, Kp, y, gamma, alpha, ms, sums_part, stream);
 }
 
-size_t ctn_split_b3_bytes(int R, int Cn) { return ctn_b3_planes_bytes(R, Cn); }
+size_t ctn_split_b3_bytes(int R, int Cn) { return ctn_b3_planes_bytes(arith_np() ? arith_np() : 3, R, Cn); }
 
 // dst[i] = bf16 piece fragments of the GEMM weight operand A [R, Cn] taken from src[i]: k_major = 0: src is stored [R, Cn];
 // k_major = 1: src is stored [Cn, R] (its transpose is the operand).  HOST arrays of device pointers; see include/ctn_hip.h.
 int ctn_split_b3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream) {
     CTN_REQUIRE(src && dst && n > 0 && R > 0 && Cn > 0, "ctn_split_b3_batch: bad arguments");
     for (int i = 0; i < n; ++i) CTN_REQUIRE(src[i] && dst[i] && aligned16(dst[i]), "ctn_split_b3_batch: matrix %d: null or unaligned pointer", i);
-    ctn_b3_launch_split(src, dst, n, R, Cn, k_major, (hipStream_t)stream);
+    CTN_REQUIRE(arith_np() != 0, "ctn_split_b3_batch: the fp32-MFMA arithmetic has no piece form");
+    ctn_b3_launch_split(arith_np(), src, dst, n, R, Cn, k_major, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_split_b3_batch");
     return CTN_OK;
 }
@@ -1158,7 +1161,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "fuse_b4")) g_ctn_block_fuse_b4 = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_mf") && (value == 16 || value == 32)) g_w4_mf = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
-    else if (!strcmp(key, "arith") && (value == 0 || value == 1)) g_arith = value;
+    else if (!strcmp(key, "arith") && value >= 0 && value <= 2) g_arith = value;
     else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 2) g_ctn_b3_tile = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
@@ -1199,7 +1202,7 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
             ctn_set_error("ctn_pw_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
             return CTN_ERR_WORKSPACE;
         }
-        const int ns = ctn_b3_launch_wgrad(a, pro_ms != nullptr, (hipStream_t)stream);
+        const int ns = ctn_b3_launch_wgrad(arith_np(), a, pro_ms != nullptr, (hipStream_t)stream);
         CTN_CHECK_LAUNCH("ctn_pw_wgrad");
         const long long nn = (long long)R * Cn;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);
@@ -1259,7 +1262,7 @@ int ctn_pw_gemm_glnbwd(const void* Wp, const float* dN, const float* y, float* O
     a.W = (const float*)Wp; a.X = dN; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.pro_part = sums_part; a.pro_nparts = nparts; a.pro_gamma = gamma; a.pro_alpha = alpha; a.pro_ms = ms; a.pro_y = y;
     a.residual = residual;
-    ctn_b3_launch_fwd(a, 2, false, true, false, false, false, (hipStream_t)stream);
+    ctn_b3_launch_fwd(arith_np(), a, 2, false, true, false, false, false, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_gemm_glnbwd");
     return CTN_OK;
 }
@@ -1286,7 +1289,7 @@ int ctn_pw_wgrad_glnbwd(const float* dN, const float* y, const float* X, float* 
         ctn_set_error("ctn_pw_wgrad_glnbwd: workspace too small (%zu < %zu)", workspace_bytes, need);
         return CTN_ERR_WORKSPACE;
     }
-    const int ns = ctn_b3_launch_wgrad(a, false, (hipStream_t)stream);
+    const int ns = ctn_b3_launch_wgrad(arith_np(), a, false, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_wgrad_glnbwd");
     const long long nn = (long long)R * Cn;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);

@@ -1,23 +1,29 @@
-// "b3" arithmetic of the 1x1-convolution GEMMs: fp32 operands multiplied on the bf16 matrix cores as TWO bf16 pieces each.
+// Split-bf16 arithmetic of the 1x1-convolution GEMMs: fp32 operands multiplied on the bf16 matrix cores as NP bf16 pieces each.
 //
-//   a = a_hi + a_lo + ra,   a_hi = bf16_rne(a),  a_lo = bf16_rne(a - a_hi)   (a - a_hi is exact in fp32; |ra| <= 2^-18 |a|)
-//   a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi         (dropped: a_lo.b_lo and the remainders, each <= 2^-18 |a.b| -- the
-//                                                     products carry >= 16 significand bits, accumulation is fp32)
+//   NP = 3, "b6" (library default -- fp32-faithful products):
+//     a = a0 + a1 + a2 EXACTLY,  a0 = bf16_rne(a), a1 = bf16_rne(a - a0), a2 = a - a0 - a1   (both differences are exact in fp32;
+//     |a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|, and a2 has at most 8 significant bits, so its conversion is exact as well)
+//     a.b ~= a2.b0 + a0.b2 + a1.b1 + a1.b0 + a0.b1 + a0.b0       six bf16 MFMAs per 16-deep step, fp32 accumulation;
+//     dropped: a1.b2 + a2.b1 + a2.b2, |.| <= (2 * 2^-24 + 2^-32) |a.b| -- the size of ONE fp32 rounding of the product, which the
+//     fp32 FMA chain of the reference commits at every step as well.  Measured against fp64 (benchmarks/b3_check.py): the error of
+//     every GEMM form is that of the fp32-MFMA kernels.
+//   NP = 2, "b3" (opt-in, faster, NOT fp32-faithful):
+//     a = a0 + a1 + ra, |ra| <= 2^-16 |a|;  a.b ~= a1.b0 + a0.b1 + a0.b0;  dropped: a1.b1 (<= 2^-16 |a.b|) and both remainder
+//     terms ra.b, a.rb (<= 2^-16 |a.b| each): products carry ~16 significant bits.
 //
-// Each piece-product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (8 x 8-bit significands).  Why: the
-// training step runs AT the 1400 W package power cap, so its time is its energy.  A 6.7-GFLOP
-// launch of the fp32-MFMA kernels costs 80-90 mJ (58-72 us under the cap), the same launch as three bf16 MFMAs per
-// 16-deep step 54-67 mJ (40-48 us) with the round-1 kernel structure (profiles/r02_d_power_lab_split.txt): the bf16
-// MFMA costs a tenth of the fp32 one per FLOP, and it overlaps the VALU work of the other waves on its SIMD, which
-// the fp32 MFMA does not.  Accuracy: the whole-model SI-SNR moves by ~1e-4 dB (budget 1e-3, tests/test_gpu_parity.py).
-// CTN_GEMM_ARITH=fp32 / ctn_tune("arith", 0) selects the bit-exact fp32-MFMA kernels of ctn_gemm.hip instead.
+// Each piece-product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (8 x 8-bit significands).  Why not the fp32
+// MFMA: it runs at 1/16 of the bf16 rate, so six bf16 MFMAs cost 3/8 of one fp32 MFMA of the same shape, and the fp32-MFMA
+// training step sits AT the 1400 W package power cap where its time is its energy.
+// CTN_GEMM_ARITH=b6|b3|fp32 / ctn_tune("arith", 2|1|0) select the arithmetic; fp32 = the fp32-MFMA kernels of ctn_gemm.hip.
 //
-// Same contracts as the fp32 kernels (PwArgs / WgArgs, prologues, epilogues, tile order, fixed-order reductions): both
-// operands are split on the fly while they are staged global -> registers -> LDS, so no entry point changes and no
-// pre-split copies exist in HBM.  Operands whose contraction index is strided in memory (activations [channel][frame],
-// weights given as [contraction][row]) are stored channel-major in LDS and read with ds_read_b64_tr_b16, the hardware
-// transposing read; operands with a contiguous contraction (stored [row][contraction] weights, both operands of the
-// weight gradient) are stored row-major and read with ds_read_b128.
+// Same contracts as the fp32 kernels (PwArgs / WgArgs, prologues, epilogues, tile order, fixed-order reductions).  Activation
+// operands are split on the fly while they are staged global -> registers -> LDS (after the fused prologue), so no pre-split
+// activation copies exist in HBM; weights are either split the same way (raw ctn_pw_gemm on fp32 weights) or pre-split once
+// per stack call into MFMA-fragment order (ctn_split_b3_batch, the product path of the composite stacks).  Operands whose
+// contraction index is strided in memory (activations [channel][frame], weights given as [contraction][row]) are stored
+// channel-major in LDS and read with ds_read_b64_tr_b16, the hardware transposing read; operands with a contiguous
+// contraction (stored [row][contraction] weights, both operands of the weight gradient) are stored row-major and read with
+// ds_read_b128.
 // Included by ctn_gemm.hip (the argument structs live in that translation unit's anonymous namespace).
 #pragma once
 #include "ctn_gemm_common.h"
@@ -27,18 +33,41 @@ namespace {
 constexpr int XK = 32;               // contraction steps per k-tile (two MFMA steps of depth 16)
 constexpr int XPA = XK + 8;          // row pitch of a row-major piece plane in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
 
-// four consecutive fp32 -> the two bf16x4 pieces (round-to-nearest-even both times)
-__device__ __forceinline__ void split2x4(const float4& v, bf16x4& hi, bf16x4& lo) {
-    hi = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    lo = bf16x4{(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]), (__bf16)(v.w - (float)hi[3])};
+// four consecutive fp32 -> NP bf16x4 pieces, most significant first (round-to-nearest-even each time; the differences are exact)
+template <int NP>
+__device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[NP]) {
+    static_assert(NP == 2 || NP == 3, "two or three pieces");
+    q[0] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    const float r0 = v.x - (float)q[0][0], r1 = v.y - (float)q[0][1], r2 = v.z - (float)q[0][2], r3 = v.w - (float)q[0][3];
+    q[1] = bf16x4{(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
+    if constexpr (NP == 3)
+        q[2] = bf16x4{(__bf16)(r0 - (float)q[1][0]), (__bf16)(r1 - (float)q[1][1]), (__bf16)(r2 - (float)q[1][2]), (__bf16)(r3 - (float)q[1][3])};
 }
 
-template <typename TL, int TRANS_W>
+// The piece products of one 16-deep step in issue order, smallest terms first: (piece of A, piece of B).
+template <int NP> struct Prods;
+template <> struct Prods<2> {
+    static constexpr int N = 3;
+    static constexpr int A[N] = {1, 0, 0}, B[N] = {0, 1, 0};
+};
+template <> struct Prods<3> {
+    static constexpr int N = 6;
+    static constexpr int A[N] = {2, 0, 1, 1, 0, 0}, B[N] = {0, 2, 1, 0, 1, 0};
+};
+// acc += sum over the piece products of a (NP fragments) and b (NP fragments)
+template <int NP>
+__device__ __forceinline__ void mfma_pieces(f32x16& acc, const bf16x8 (&fa)[NP], const bf16x8 (&fb)[NP]) {
+#pragma unroll
+    for (int t = 0; t < Prods<NP>::N; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[Prods<NP>::A[t]], fb[Prods<NP>::B[t]], acc, 0, 0, 0);
+}
+
+template <typename TL, int TRANS_W, int NP>
 struct B3 {
     static constexpr int PB = TL::TN + 32;                                   // pitch of a channel-major plane row in bf16
     static constexpr int PA = TL::TM + 32;
-    static constexpr int A_ELEMS = TRANS_W ? 2 * XK * PA : 2 * TL::TM * XPA;  // bf16 elements, both pieces
-    static constexpr int B_ELEMS = 2 * XK * PB;
+    static constexpr int A_ELEMS = TRANS_W ? NP * XK * PA : NP * TL::TM * XPA;  // bf16 elements, all pieces
+    static constexpr int B_ELEMS = NP * XK * PB;
     static constexpr int MAIN_BYTES = (A_ELEMS + B_ELEMS) * 2;
     static constexpr int STAGE_BYTES = TL::STAGE_FLOATS * 4;
     static constexpr int SMEM_BYTES = MAIN_BYTES > STAGE_BYTES ? MAIN_BYTES : STAGE_BYTES;
@@ -58,19 +87,19 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane_at_tile, int P, in
     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename TL, int TRANS_W, int PRO, int EPI>
-__global__ __launch_bounds__(TL::NTH, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192) ? 3 : 2))
+template <int NP, typename TL, int TRANS_W, int PRO, int EPI>
+__global__ __launch_bounds__(TL::NTH, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192 && NP == 2) ? 3 : 2))
 void pw_gemm_b3_kernel(PwArgs a) {
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, NTH = TL::NTH;
-    using L = B3<TL, TRANS_W>;
+    using L = B3<TL, TRANS_W, NP>;
     constexpr int PB = L::PB, PA = L::PA;
     constexpr int B_L = XK * TN / 4 / NTH, A_L = XK * TM / 4 / NTH;         // float4 loads per thread per k-tile
     constexpr int AT = XK / 4;                                              // threads per stored weight row (TRANS_W = 0)
     static_assert(A_L >= 1 && B_L >= 1, "tile too small for the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[L::SMEM_BYTES];
     __shared__ double red[NTH / 64];
-    __bf16* const Ap = reinterpret_cast<__bf16*>(smem_raw);        // TRANS_W: [2][XK][PA]   else [2][TM][XPA]
-    __bf16* const Bp = Ap + L::A_ELEMS;                            // [2][XK][PB]
+    __bf16* const Ap = reinterpret_cast<__bf16*>(smem_raw);        // TRANS_W: [NP][XK][PA]   else [NP][TM][XPA]
+    __bf16* const Bp = Ap + L::A_ELEMS;                            // [NP][XK][PB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / TL::WGN, wn = wave % TL::WGN;
@@ -132,16 +161,16 @@ void pw_gemm_b3_kernel(PwArgs a) {
     auto store_tile = [&](const float4 (&ra)[A_L], const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
-            bf16x4 hi, lo;
-            split2x4(ra[j], hi, lo);
+            bf16x4 q[NP];
+            split_x4<NP>(ra[j], q);
             if constexpr (TRANS_W == 0) {
                 const int r = tid / AT + (NTH / AT) * j, c = (tid % AT) * 4;
-                *reinterpret_cast<bf16x4*>(Ap + r * XPA + c) = hi;
-                *reinterpret_cast<bf16x4*>(Ap + (TM + r) * XPA + c) = lo;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(Ap + (p * TM + r) * XPA + c) = q[p];
             } else {
                 const int c = tid / (TM / 4) + (4 * NTH / TM) * j, r = (tid % (TM / 4)) * 4;
-                *reinterpret_cast<bf16x4*>(Ap + c * PA + r) = hi;
-                *reinterpret_cast<bf16x4*>(Ap + (XK + c) * PA + r) = lo;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(Ap + (p * XK + c) * PA + r) = q[p];
             }
         }
 #pragma unroll
@@ -149,10 +178,10 @@ void pw_gemm_b3_kernel(PwArgs a) {
             const int i = tid / (TN / 4) + (4 * NTH / TN) * j, k = (tid % (TN / 4)) * 4;
             float4 v = rb[j];
             if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
-            bf16x4 hi, lo;
-            split2x4(v, hi, lo);
-            *reinterpret_cast<bf16x4*>(Bp + i * PB + k) = hi;
-            *reinterpret_cast<bf16x4*>(Bp + (XK + i) * PB + k) = lo;
+            bf16x4 q[NP];
+            split_x4<NP>(v, q);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(Bp + (p * XK + i) * PB + k) = q[p];
         }
     };
 
@@ -168,11 +197,11 @@ void pw_gemm_b3_kernel(PwArgs a) {
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < XK / 16; ++ks) {
-            bf16x8 af[MT][2], bfr[NTL][2];
+            bf16x8 af[MT][NP], bfr[NTL][NP];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     if constexpr (TRANS_W == 0)
                         af[i][p] = *reinterpret_cast<const bf16x8*>(Ap + (p * TM + wm * WM + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
                     else
@@ -181,15 +210,11 @@ void pw_gemm_b3_kernel(PwArgs a) {
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) bfr[j][p] = frag_tr(Bp + (p * XK + ks * 16) * PB + wn * WN + j * 32, PB, lane);
+                for (int p = 0; p < NP; ++p) bfr[j][p] = frag_tr(Bp + (p * XK + ks * 16) * PB + wn * WN + j * 32, PB, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) {      // small terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NTL; ++j) mfma_pieces<NP>(acc[i][j], af[i], bfr[j]);      // small terms first
         }
     };
 
@@ -221,10 +246,10 @@ constexpr int WNT = 512;
 // APRO: gLN'/PReLU' backward applied on the fly to the dOut operand (the B4 pass of DESIGN.md folded into this kernel and
 // into the input-gradient GEMM: dOut stays the raw gradient with respect to the norm's output); the workgroups of column
 // tile 0 also sum the PReLU-slope gradient of their rows and frames.
-template <int PRO, int APRO>
+template <int NP, int PRO, int APRO>
 __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a) {
-    constexpr int PLANE = BM * XPA, STAGE = 2 * PLANE;        // bf16 elements: one piece plane, both pieces of one operand
-    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * STAGE];          // [stage][piece][BM][XPA]
+    constexpr int PLANE = BM * XPA, STAGE = NP * PLANE;       // bf16 elements: one piece plane, all pieces of one operand
+    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * STAGE];          // [stage][piece][BM][XPA]   (NP = 3: 2 x 60 KiB)
     __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * STAGE];
     __shared__ double red[WNT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,10 +313,10 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
         }
     };
     auto write_one = [&](__bf16* P, int row, const float4& v) {
-        bf16x4 hi, lo;
-        split2x4(v, hi, lo);
-        *reinterpret_cast<bf16x4*>(P + row * XPA + kq) = hi;
-        *reinterpret_cast<bf16x4*>(P + PLANE + row * XPA + kq) = lo;
+        bf16x4 q[NP];
+        split_x4<NP>(v, q);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(P + p * PLANE + row * XPA + kq) = q[p];
     };
     auto write_lds = [&](int kt, int stage, const float4 (&qa)[2], const float4 (&qb)[2], const float4 (&qy)[2]) {
 #pragma unroll
@@ -327,20 +352,16 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
         const __bf16* const Bs = Bp + stage * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][2], bfr[2];
+            bf16x8 af[2][NP], bfr[NP];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + (wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
                 bfr[p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + (wn * 32 + l31) * XPA + ks * 16 + lhi * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[0], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[1], acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[0], acc[i], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i) mfma_pieces<NP>(acc[i], af[i], bfr);
         }
     };
     // Register ring of PF k-tiles: at the top of iteration kt, LDS stage kt % 2 holds tile kt, ring slots (kt + 1 .. kt + PF - 1)
@@ -399,10 +420,10 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
 // 8 values), 4 ds_write_b64, 16 ds_read_b64_tr_b16, 12 MFMAs.
 // The MFMA order per accumulator is that of pw_gemm_b3_kernel (lo.hi, hi.lo, hi.hi per 16-deep step): same values.
 // ---------------------------------------------------------------------------------------------------------
-template <typename TL>
+template <typename TL, int NP>
 struct B3P {
     static constexpr int PB = TL::TN + 32;
-    static constexpr int STAGE_ELEMS = 2 * XK * PB;                            // both pieces of one k-tile
+    static constexpr int STAGE_ELEMS = NP * XK * PB;                           // all pieces of one k-tile
     static constexpr int MAIN_BYTES = 2 * STAGE_ELEMS * 2;                     // two stages
     static constexpr int EPI_BYTES = TL::STAGE_FLOATS * 4;
     static constexpr int SMEM_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
@@ -412,12 +433,12 @@ __device__ __forceinline__ bf16x8 buf_ld_frag(__amdgpu_buffer_rsrc_t r, int voff
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0));
 }
 
-template <typename TL, int PRO, int EPI>
-__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? 4 : 2)
+template <int NP, typename TL, int PRO, int EPI>
+__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? (NP == 2 ? 4 : 3) : 2)
 void pw_gemm_b3p_kernel(PwArgs a) {
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, NTH = TL::NTH;
     static_assert(TL::WGN == 1, "each wave owns its rows: 4 x 1 wave grid");
-    using L = B3P<TL>;
+    using L = B3P<TL, NP>;
     constexpr int PB = L::PB;
     constexpr int B_L = XK * TN / 4 / NTH;                                     // float4 loads per thread per k-tile
     static_assert(B_L >= 1, "tile too narrow for the workgroup");
@@ -447,7 +468,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     const int nk = (a.Cn + XK - 1) / XK, Cnp = nk * XK;
     const int Rp = (a.R + 31) / 32 * 32;
     // weight fragments: rows past Rp fall off the end of the planes and read 0 (rows R .. Rp-1 are stored as zeros)
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)Rp * (unsigned)Cnp * 4u);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)Rp * (unsigned)Cnp * (2u * NP));
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
     __amdgpu_buffer_rsrc_t rsG = rsX, rsBt = rsX, rsY = rsX;
     if constexpr (PRO == PRO_PRELU_NORM) {
@@ -460,7 +481,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     }
     int voA[MT], voB[B_L], voP[B_L];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) voA[i] = ((r0 + wm * WM) / 32 + i) * (Cnp / 16) * 2048 + lane * 16;      // 2 KiB per (rt, kt)
+    for (int i = 0; i < MT; ++i) voA[i] = ((r0 + wm * WM) / 32 + i) * (Cnp / 16) * (NP * 1024) + lane * 16;      // NP KiB per (rt, 16-deep step)
 #pragma unroll
     for (int j = 0; j < B_L; ++j) {
         const int i = tid / (TN / 4) + (4 * NTH / TN) * j;
@@ -469,13 +490,13 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     }
     const int sB = XK * a.Kp * 4;
 
-    auto load_a = [&](int kt, bf16x8 (&fa)[MT][2][2]) {          // [row tile][k step][piece]
+    auto load_a = [&](int kt, bf16x8 (&fa)[MT][2][NP]) {         // [row tile][k step][piece]
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) fa[i][ks][p] = buf_ld_frag(rsW, voA[i] + kt * 4096, (ks * 2 + p) * 1024);
+                for (int p = 0; p < NP; ++p) fa[i][ks][p] = buf_ld_frag(rsW, voA[i] + kt * (2 * NP * 1024), (ks * NP + p) * 1024);
     };
     auto load_b = [&](int kt, float4 (&rb)[B_L], float2 (&rp)[B_L], float4 (&ry)[B_L]) {
 #pragma unroll
@@ -505,10 +526,10 @@ void pw_gemm_b3p_kernel(PwArgs a) {
                 v.z = gln_bwd_elem(v.z, ry[j].z, rg, gq, c0 + k + 2 < a.K, dal);
                 v.w = gln_bwd_elem(v.w, ry[j].w, rg, gq, c0 + k + 3 < a.K, dal);
             }
-            bf16x4 hi, lo;
-            split2x4(v, hi, lo);
-            *reinterpret_cast<bf16x4*>(S + i * PB + k) = hi;
-            *reinterpret_cast<bf16x4*>(S + (XK + i) * PB + k) = lo;
+            bf16x4 q[NP];
+            split_x4<NP>(v, q);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(S + (p * XK + i) * PB + k) = q[p];
         }
     };
 
@@ -520,29 +541,25 @@ void pw_gemm_b3p_kernel(PwArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto compute = [&](int stage, const bf16x8 (&fa)[MT][2][2]) {
+    auto compute = [&](int stage, const bf16x8 (&fa)[MT][2][NP]) {
         const __bf16* const S = Bp + stage * L::STAGE_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[NTL][2];
+            bf16x8 bfr[NTL][NP];
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) bfr[j][p] = frag_tr(S + (p * XK + ks * 16) * PB + j * 32, PB, lane);
+                for (int p = 0; p < NP; ++p) bfr[j][p] = frag_tr(S + (p * XK + ks * 16) * PB + j * 32, PB, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][1], bfr[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][0], bfr[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ks][0], bfr[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NTL; ++j) mfma_pieces<NP>(acc[i][j], fa[i][ks], bfr[j]);
         }
     };
 
     // k-tile kt: weight fragments in one register set, activation tile in LDS stage kt & 1; while it is multiplied, tile
     // kt + 1 (already in registers) is split into the other stage and the loads of tile kt + 2 are issued.
-    bf16x8 fa0[MT][2][2], fa1[MT][2][2];
+    bf16x8 fa0[MT][2][NP], fa1[MT][2][NP];
     float4 rb[B_L], ry[B_L];
     float2 rp[B_L];
     load_a(0, fa0);
@@ -573,6 +590,7 @@ struct SplitArgs {
     __bf16* dst[SPLIT_MAX];
     int R, Cn, sr, sk, nkt;        // nkt = Cnp / 16
 };
+template <int NP>
 __global__ __launch_bounds__(256) void split_b3_kernel(SplitArgs a) {
     const float* __restrict__ W = a.src[blockIdx.z];
     __bf16* __restrict__ D = a.dst[blockIdx.z];
@@ -583,50 +601,50 @@ __global__ __launch_bounds__(256) void split_b3_kernel(SplitArgs a) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (r < a.R && k0 + e < a.Cn) ? W[(size_t)r * a.sr + (size_t)(k0 + e) * a.sk] : 0.f;
-    bf16x4 h0, l0, h1, l1;
-    split2x4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
-    split2x4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
-    __bf16* const blk = D + ((size_t)(rt * a.nkt + kt) * 2) * 512 + lane * 8;      // 512 bf16 = 1 KiB per block
-    *reinterpret_cast<bf16x8*>(blk) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    *reinterpret_cast<bf16x8*>(blk + 512) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    bf16x4 q0[NP], q1[NP];
+    split_x4<NP>(make_float4(v[0], v[1], v[2], v[3]), q0);
+    split_x4<NP>(make_float4(v[4], v[5], v[6], v[7]), q1);
+    __bf16* const blk = D + ((size_t)(rt * a.nkt + kt) * NP) * 512 + lane * 8;     // 512 bf16 = 1 KiB per block
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8*>(blk + p * 512) = __builtin_shufflevector(q0[p], q1[p], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename TL>
+template <int NP, typename TL>
 void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
-    else if (a.pro_y != nullptr) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_GLN_BWD, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-    else if (residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (relu) hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_gemm_b3p_kernel<TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    else if (a.pro_y != nullptr) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_GLN_BWD, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
 }
 
-template <typename TL>
+template <int NP, typename TL>
 void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
-        if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else if (pro) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-        else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-        else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+        if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else if (pro) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+        else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+        else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
     } else if (pro) {
-        if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    } else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-    else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (relu) hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_gemm_b3_kernel<TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+        if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
 }
 
 }  // namespace
 
-// ---- host side, used by the entry points of ctn_gemm.hip ---------------------------------------------------------
-static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step 11.56 / 11.20 / 11.50 ms
+// ---- host side, used by the entry points of ctn_gemm.hip (np = pieces per operand: 3 = b6, 2 = b3) ---------------------------
+static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step (b3) 11.56 / 11.20 / 11.50 ms
 static int g_ctn_b3_wgrad_blocks = 256;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
 static void ctn_b3_tile_dims(int* tm, int* tn) {
@@ -635,31 +653,37 @@ static void ctn_b3_tile_dims(int* tm, int* tn) {
     *tn = d[g_ctn_b3_tile][1];
 }
 
-static void ctn_b3_launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
-    int tm, tn;
-    ctn_b3_tile_dims(&tm, &tn);
-    a.tiles_r = ctn_cdiv(a.R, tm);
-    a.tiles_c = ctn_cdiv(a.Kp, tn);
+template <int NP>
+static void ctn_b3_launch_fwd_np(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     if (trans_w == 2) {             // a.W = fragment-ordered pieces (ctn_split_b3_batch)
         switch (g_ctn_b3_tile) {
-            case 1: launch_b3p_tile<Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
-            case 2: launch_b3p_tile<Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
-            default: launch_b3p_tile<Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            case 1: launch_b3p_tile<NP, Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            case 2: launch_b3p_tile<NP, Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            default: launch_b3p_tile<NP, Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
         }
         return;
     }
     switch (g_ctn_b3_tile) {
-        case 1: launch_b3_tile<T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 2: launch_b3_tile<Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        default: launch_b3_tile<T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 1: launch_b3_tile<NP, T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        case 2: launch_b3_tile<NP, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        default: launch_b3_tile<NP, T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
     }
 }
 
-static size_t ctn_b3_planes_bytes(int R, int Cn) {
-    return (size_t)((R + 31) / 32 * 32) * (size_t)((Cn + XK - 1) / XK * XK) * 4;
+static void ctn_b3_launch_fwd(int np, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    int tm, tn;
+    ctn_b3_tile_dims(&tm, &tn);
+    a.tiles_r = ctn_cdiv(a.R, tm);
+    a.tiles_c = ctn_cdiv(a.Kp, tn);
+    if (np == 3) ctn_b3_launch_fwd_np<3>(a, trans_w, pro, residual, stats, relu, gln_bwd, st);
+    else ctn_b3_launch_fwd_np<2>(a, trans_w, pro, residual, stats, relu, gln_bwd, st);
 }
 
-static void ctn_b3_launch_split(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, hipStream_t st) {
+static size_t ctn_b3_planes_bytes(int np, int R, int Cn) {
+    return (size_t)((R + 31) / 32 * 32) * (size_t)((Cn + XK - 1) / XK * XK) * 2 * (size_t)np;
+}
+
+static void ctn_b3_launch_split(int np, const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, hipStream_t st) {
     for (int o = 0; o < n; o += SPLIT_MAX) {
         SplitArgs sa{};
         const int cnt = n - o < SPLIT_MAX ? n - o : SPLIT_MAX;
@@ -670,7 +694,9 @@ static void ctn_b3_launch_split(const void* const* src, void* const* dst, int n,
         sa.R = R; sa.Cn = Cn;
         sa.sr = k_major ? 1 : Cn; sa.sk = k_major ? R : 1;
         sa.nkt = (Cn + XK - 1) / XK * 2;
-        hipLaunchKernelGGL(split_b3_kernel, dim3(ctn_cdiv(sa.nkt, 4), (R + 31) / 32, cnt), dim3(256), 0, st, sa);
+        const dim3 grid(ctn_cdiv(sa.nkt, 4), (R + 31) / 32, cnt);
+        if (np == 3) hipLaunchKernelGGL(split_b3_kernel<3>, grid, dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL(split_b3_kernel<2>, grid, dim3(256), 0, st, sa);
     }
 }
 
@@ -685,14 +711,21 @@ static void ctn_b3_wgrad_plan(int M, int R, int Cn, int Kp, int* chunk, int* chu
     *chunks_per_m = ctn_cdiv(Kp, c);
 }
 
+template <int NP>
+static void ctn_b3_launch_wgrad_np(const WgArgs& a, bool pro, dim3 grid, hipStream_t st) {
+    const dim3 block(WNT);
+    if (a.a_y != nullptr) hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_NONE, 1>), grid, block, 0, st, a);      // (the dW1 form: no X prologue)
+    else if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_PRELU_NORM, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_NONE, 0>), grid, block, 0, st, a);
+}
+
 // a.chunk / a.chunks_per_m / a.slab already set by the caller from ctn_b3_wgrad_plan; returns the number of slabs
-static int ctn_b3_launch_wgrad(WgArgs& a, bool pro, hipStream_t st) {
+static int ctn_b3_launch_wgrad(int np, WgArgs& a, bool pro, hipStream_t st) {
     a.tiles_r = ctn_cdiv(a.R, BM);
     a.tiles_c = ctn_cdiv(a.Cn, BN);
     const int nsplit = a.M * a.chunks_per_m;
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit)), block(WNT);
-    if (a.a_y != nullptr) hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_NONE, 1>), grid, block, 0, st, a);      // (the dW1 form: no X prologue)
-    else if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_PRELU_NORM, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<PRO_NONE, 0>), grid, block, 0, st, a);
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit));
+    if (np == 3) ctn_b3_launch_wgrad_np<3>(a, pro, grid, st);
+    else ctn_b3_launch_wgrad_np<2>(a, pro, grid, st);
     return nsplit;
 }

@@ -123,17 +123,23 @@ def _read_manifest(json_dir, name):
         return json.load(f)
 
 
-def shard_plan(plan, rank, world, equal_counts):
-    """This rank's minibatches of a planned epoch: plan[rank::world].
+def shard_plan(plan, rank, world, equal_counts, epoch=0):
+    """This rank's minibatches of a planned epoch.
 
     equal_counts (training): every step ends in a gradient all-reduce, so all ranks must run the SAME number of steps --
     the remainder len(plan) % world is dropped (at most world - 1 minibatches per epoch; the reference's single process
-    has no such constraint, src/data.py:82-113).  Ragged minibatch SIZES stay exact: the Solver weights each rank's
-    gradient by its share of the global minibatch.  Validation minibatches have no per-step collective and keep all."""
+    has no such constraint, src/data.py:82-113).  The plan is built from length-sorted utterances, so a static cut would
+    drop the same minibatches and deal every rank the same subset in every epoch: the plan is first permuted with a
+    generator seeded by the epoch alone (identical on every rank), so the dropped remainder and the rank assignment change
+    from epoch to epoch and every minibatch is trained on over a run (AudioDataset.set_epoch).  Ragged minibatch SIZES stay
+    exact: the Solver weights each rank's gradient by its share of the global minibatch.  Validation minibatches have no
+    per-step collective, keep their order and keep all."""
     if world <= 1:
         return plan
     if equal_counts:
-        plan = plan[: len(plan) // world * world]
+        g = torch.Generator().manual_seed(0x5eed + int(epoch))
+        order = torch.randperm(len(plan), generator=g).tolist()
+        plan = [plan[i] for i in order][: len(plan) // world * world]
     return plan[rank::world]
 
 
@@ -156,7 +162,13 @@ class AudioDataset(data.Dataset):
         else:
             self.segment_len = -1
             plan = plan_full_utterance_minibatches(lengths, batch_size, sample_rate, cv_maxlen, max_hours)
+        self.full_plan, self.rank, self.world = plan, rank, world
         self.plan = shard_plan(plan, rank, world, equal_counts=segment >= 0.0)
+
+    def set_epoch(self, epoch):
+        """Re-deal the training minibatches over the ranks for this epoch (same permutation on every rank; a no-op for one
+        process and for full-utterance validation sets).  The Solver calls it at the top of every epoch."""
+        self.plan = shard_plan(self.full_plan, self.rank, self.world, equal_counts=self.segment_len >= 0, epoch=epoch)
 
     def __len__(self):
         return len(self.plan)

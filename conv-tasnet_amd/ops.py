@@ -25,8 +25,8 @@ F32 = torch.float32
 F64 = torch.float64
 BF16 = torch.bfloat16
 
-# GEMM arithmetic: "fp32" = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains), the product path.  "x6" = the split-bf16
-# experiment (include/ctn_hip_experimental.h): only with a CTN_BUILD_X6=1 library and CTN_EXPERIMENTAL=1.
+# _GEMM_MODE "x6" = the round-1 split-bf16 experiment (include/ctn_hip_experimental.h): only with a CTN_BUILD_X6=1 library
+# and CTN_EXPERIMENTAL=1.  The product arithmetics (b6 default / fp32 / b3) are selected by set_gemm_arith below.
 _GEMM_MODE = "fp32"
 
 
@@ -49,17 +49,21 @@ def gemm_mode():
     return _GEMM_MODE
 
 
+_ARITH_NAMES = ("fp32", "b3", "b6")        # ids of ctn_gemm_arith / ctn_tune("arith", id)
+
+
 def gemm_arith():
-    """'b3' (default: two bf16 pieces per fp32 operand, three bf16 MFMAs, fp32 accumulation) or 'fp32' (fp32-MFMA kernels)."""
-    return "b3" if lib.ctn_gemm_arith() else "fp32"
+    """'b6' (default: three bf16 pieces per fp32 operand, six bf16 MFMAs, fp32 accumulation -- fp32-faithful products),
+    'fp32' (fp32-MFMA kernels, bit-exact fp32 FMA chains) or 'b3' (opt-in: two pieces, three MFMAs, ~16-bit products)."""
+    return _ARITH_NAMES[lib.ctn_gemm_arith()]
 
 
 def set_gemm_arith(name):
     """Select the arithmetic of every 1x1-convolution GEMM (include/ctn_hip.h: ctn_gemm_arith).  Change it between steps
     only: statistics layouts and workspace sizes depend on it (the cached workspaces are dropped here)."""
-    if name not in ("b3", "fp32"):
-        raise ValueError("gemm arithmetic must be 'b3' or 'fp32'")
-    lib.call("ctn_tune", b"arith", 1 if name == "b3" else 0)
+    if name not in _ARITH_NAMES:
+        raise ValueError("gemm arithmetic must be one of %s" % (_ARITH_NAMES,))
+    lib.call("ctn_tune", b"arith", _ARITH_NAMES.index(name))
     _ws_cache.clear()
 
 
@@ -169,7 +173,7 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
         return out, epi_part
     tw = int(trans_w)
     if _b3_planes_ok(R) and not relu_out:
-        W, tw = _b3_pieces(W, R, Cn, bool(trans_w)), 2           # the product kernel of the b3 arithmetic (pre-split weights)
+        W, tw = _b3_pieces(W, R, Cn, bool(trans_w)), 2           # the product kernel of the split-bf16 arithmetics (pre-split weights)
     lib.call("ctn_pw_gemm", _p(W), _p(X), _p(out), M, R, Cn, K, Kp, tw,
              _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
              int(relu_out), _stream())
@@ -177,7 +181,7 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
 
 
 def _b3_planes_ok(R):
-    return R >= 64 and lib.ctn_gemm_arith() == 1
+    return R >= 64 and lib.ctn_gemm_arith() != 0
 
 
 def _b3_pieces(W, R, Cn, k_major):
@@ -575,6 +579,9 @@ class TcnGln(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.acts is None:
+            raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
+                           "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
         x0, xs, h1s, ds, ms = ctx.acts
         params = ctx.params
         K, dil, nb, causal, P = ctx.cfg
@@ -659,6 +666,9 @@ class TcnCln(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.acts is None:
+            raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
+                           "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
         x0, xs, hs, st = ctx.acts
         params = ctx.params
         K, dil, nb, causal, P = ctx.cfg
@@ -786,12 +796,38 @@ def bn_bwd(dOut, Y, alpha, weight, mr, training, K):
     return dY, dg, db, dalpha
 
 
+class _bn_arith:
+    """BatchNorm blocks never run on the opt-in b3 arithmetic: near-constant channels (rstd ~ 1e4 at random init) amplify
+    its ~16-bit product noise to tens of percent of a BN layer's gradient.  Under b3 their GEMMs use the default b6."""
+
+    def __enter__(self):
+        self.prev = gemm_arith()
+        if self.prev == "b3":
+            set_gemm_arith("b6")
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev == "b3":
+            set_gemm_arith("b3")
+        return False
+
+
 class BnBlock(torch.autograd.Function):
     """TemporalBlock with norm_type="BN" (src/conv_tasnet.py:218-244,305-309): same chain as ClnBlock with the two
     norms replaced by (PReLU +) BatchNorm1d.  bn1 / bn2 = (running_mean, running_var, training, eps, momentum)."""
 
     @staticmethod
-    def forward(ctx, x, w1, a1, g1, b1, D, a2, g2, b2, w2, K, dilation, causal, bn1, bn2):
+    def forward(ctx, *args):
+        with _bn_arith():
+            return BnBlock._forward(ctx, *args)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with _bn_arith():
+            return BnBlock._backward(ctx, dout)
+
+    @staticmethod
+    def _forward(ctx, x, w1, a1, g1, b1, D, a2, g2, b2, w2, K, dilation, causal, bn1, bn2):
         x = _c(x)
         M, B, Kp = x.shape
         H = w1.shape[0]
@@ -808,7 +844,7 @@ class BnBlock(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def _backward(ctx, dout):
         x, h1, n1, d, n2, mr1, mr2, w1, a1, g1, D, a2, g2, w2 = ctx.saved_tensors
         K, dilation, causal, tr1, tr2 = ctx.cfg
         dout = _c(dout)

@@ -202,6 +202,8 @@ class Solver(object):
 
     def _run_one_epoch(self, epoch, cross_valid=False):
         loader = self.cv_loader if cross_valid else self.tr_loader
+        if not cross_valid and hasattr(getattr(loader, "dataset", None), "set_epoch"):
+            loader.dataset.set_epoch(epoch)         # N > 1: another deal of the minibatches over the ranks every epoch
         dev = next(self.model.parameters()).device
         world = parallel.world_size()
         t0, running, n = time.time(), 0.0, 0

@@ -66,9 +66,26 @@ def test_rank_sharding_partitions_the_plan(manifest):
         parts = [D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader, rank=r, world=world).plan
                  for r in range(world)]
         assert len(set(len(p) for p in parts)) == 1 and len(parts[0]) == len(full) // world
-        kept = full[: len(full) // world * world]
-        assert sorted(map(tuple, sum(parts, []))) == sorted(map(tuple, kept))
-        assert sum(len(set(map(tuple, p))) for p in parts) == len(set(map(tuple, kept)))
+        dealt = sum(parts, [])
+        assert len(dealt) == len(full) // world * world                       # disjoint: every kept minibatch exactly once
+        assert len(set(map(tuple, dealt))) == len(dealt) and set(map(tuple, dealt)) <= set(map(tuple, full))
+        # the deal changes with the epoch (same permutation on every rank), so over a run every minibatch is trained on and
+        # no rank keeps a fixed subset of the length-sorted plan
+        dss = [D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader, rank=r, world=world) for r in range(world)]
+        seen, rank0 = set(), []
+        for epoch in range(12):
+            for ds in dss:
+                ds.set_epoch(epoch)
+            ep = sum((ds.plan for ds in dss), [])
+            assert len(set(map(tuple, ep))) == len(ep) == len(full) // world * world
+            seen |= set(map(tuple, ep))
+            rank0.append(tuple(map(tuple, dss[0].plan)))
+        assert len(set(rank0)) > 1
+        if len(full) % world:
+            assert seen == set(map(tuple, full))
+        one = D.AudioDataset(jdir, batch_size=3, segment=0.5, reader=synth_reader)
+        one.set_epoch(5)
+        assert one.plan == full                                               # single process: the reference's plan, untouched
         cv_full = D.AudioDataset(jdir, batch_size=1, segment=-1, cv_maxlen=100, reader=synth_reader).plan
         cv_parts = [D.AudioDataset(jdir, batch_size=1, segment=-1, cv_maxlen=100, reader=synth_reader, rank=r, world=world).plan
                     for r in range(world)]
