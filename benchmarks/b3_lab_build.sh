@@ -1,9 +1,16 @@
-# builds the phase-ablation variants of the b3 kernels next to the product library (local, cross-compile): benchmarks/lab_b3_<tag>.so
+# builds the phase-ablation variants of the split-bf16 GEMM kernels next to the product library (local, cross-compile):
+# benchmarks/lab_b3_<tag>.so   (the hooks are #ifdef CTN_EXP_B3_<tag> in csrc/ctn_gemm_b3.h; never defined in the product build)
 set -e
 cd "$(dirname "$0")/.."
-for tag in NK1 NOEPI NOCOMPUTE NOSTORE; do
-  CTN_EXTRA_HIPCC_FLAGS=-DCTN_EXP_B3_$tag python conv-tasnet_amd/_build.py --force > /dev/null 2>&1
-  cp conv-tasnet_amd/libctn_hip.so benchmarks/lab_b3_$tag.so
+TAGS="${TAGS:-NK1 NOEPI NOMFMA NOA NOSPLIT NOLDSRD}"
+mkdir -p /tmp/lab_objs
+HIPCC=/opt/rocm/bin/hipcc
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form"
+python conv-tasnet_amd/_build.py > /dev/null
+OBJS=$(ls conv-tasnet_amd/csrc/build/*.o | grep -v ctn_gemm.o)
+for tag in $TAGS; do
+  ( $HIPCC $FLAGS -DCTN_EXP_B3_$tag -c conv-tasnet_amd/csrc/ctn_gemm.hip -o /tmp/lab_objs/ctn_gemm_$tag.o && \
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o benchmarks/lab_b3_$tag.so $OBJS /tmp/lab_objs/ctn_gemm_$tag.o ) &
 done
-python conv-tasnet_amd/_build.py --force > /dev/null 2>&1
+wait
 ls -la benchmarks/lab_b3_*.so

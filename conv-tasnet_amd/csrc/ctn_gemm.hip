@@ -934,6 +934,11 @@ extern "C" int ctn_debug_read(unsigned long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ctn_dbg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef CTN_EXP_B3_TIMELINE
+extern "C" int ctn_debug_timeline(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ctn_dbg_tl), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---- persistent kernel: selection and launch ---------------------------------------------------------------
 // Default: the one-tile-per-workgroup kernels (pw_gemm_kernel).  The persistent kernels are 5-13 % faster launched alone
@@ -1163,6 +1168,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
     else if (!strcmp(key, "arith") && value >= 0 && value <= 2) g_arith = value;
     else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 2) g_ctn_b3_tile = value;
+    else if (!strcmp(key, "b3_tile_k3") && value >= 0 && value <= 2) g_ctn_b3_tile_k3 = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;

@@ -33,15 +33,29 @@ namespace {
 constexpr int XK = 32;               // contraction steps per k-tile (two MFMA steps of depth 16)
 constexpr int XPA = XK + 8;          // row pitch of a row-major piece plane in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
 
-// four consecutive fp32 -> NP bf16x4 pieces, most significant first (round-to-nearest-even each time; the differences are exact)
+// four consecutive fp32 -> NP bf16x4 pieces, most significant first (round-to-nearest-even each time; the differences are exact).
+// Written on packed pairs: one v_cvt_pk_bf16_f32 per pair and piece, the bf16 -> fp32 widening as a shift / mask of the packed
+// register -- 5.5 VALU instructions per element for three pieces (the element-wise form compiled to 7.5).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v));
+}
+__device__ __forceinline__ float pk_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float pk_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 template <int NP>
 __device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[NP]) {
     static_assert(NP == 2 || NP == 3, "two or three pieces");
-    q[0] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-    const float r0 = v.x - (float)q[0][0], r1 = v.y - (float)q[0][1], r2 = v.z - (float)q[0][2], r3 = v.w - (float)q[0][3];
-    q[1] = bf16x4{(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
-    if constexpr (NP == 3)
-        q[2] = bf16x4{(__bf16)(r0 - (float)q[1][0]), (__bf16)(r1 - (float)q[1][1]), (__bf16)(r2 - (float)q[1][2]), (__bf16)(r3 - (float)q[1][3])};
+    const unsigned h0 = pk_bf16(v.x, v.y), h1 = pk_bf16(v.z, v.w);
+    const float r0 = v.x - pk_lo(h0), r1 = v.y - pk_hi(h0), r2 = v.z - pk_lo(h1), r3 = v.w - pk_hi(h1);
+    const unsigned m0 = pk_bf16(r0, r1), m1 = pk_bf16(r2, r3);
+    q[0] = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
+    q[1] = __builtin_bit_cast(bf16x4, u32x2v{m0, m1});
+    if constexpr (NP == 3) {
+        const unsigned l0 = pk_bf16(r0 - pk_lo(m0), r1 - pk_hi(m0)), l1 = pk_bf16(r2 - pk_lo(m1), r3 - pk_hi(m1));
+        q[2] = __builtin_bit_cast(bf16x4, u32x2v{l0, l1});
+    }
 }
 
 // The piece products of one 16-deep step in issue order, smallest terms first: (piece of A, piece of B).
@@ -433,6 +447,14 @@ __device__ __forceinline__ bf16x8 buf_ld_frag(__amdgpu_buffer_rsrc_t r, int voff
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0));
 }
 
+#ifdef CTN_EXP_B3_TIMELINE       // experiment builds only: per-workgroup phase stamps (benchmarks/b3_timeline.py)
+__device__ unsigned long long ctn_dbg_tl[8192 * 12];
+#define CTN_TL_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) { ctn_dbg_tl[blockIdx.x * 12 + 2 * (i)] = __builtin_amdgcn_s_memtime(); \
+                                  ctn_dbg_tl[blockIdx.x * 12 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define CTN_TL_STAMP(i) do { } while (0)
+#endif
+
 template <int NP, typename TL, int PRO, int EPI>
 __global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? (NP == 2 ? 4 : 3) : 2)
 void pw_gemm_b3p_kernel(PwArgs a) {
@@ -447,6 +469,13 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     __bf16* const Bp = reinterpret_cast<__bf16*>(smem_raw);                    // [stage][piece][XK][PB]
 
     const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    CTN_TL_STAMP(0);
+#ifdef CTN_EXP_B3_TIMELINE
+    if (tid == 0 && blockIdx.x < 8192) {
+        ctn_dbg_tl[blockIdx.x * 12 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+        ctn_dbg_tl[blockIdx.x * 12 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+    }
+#endif
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int rt = bid % a.tiles_r; bid /= a.tiles_r;
     const int ct = bid % a.tiles_c;
@@ -465,7 +494,11 @@ void pw_gemm_b3p_kernel(PwArgs a) {
             a.pro_ms_out[2 * m + 1] = p_rstd;
         }
     }
+#ifdef CTN_EXP_B3_NK1
+    const int nk = 1, Cnp = (a.Cn + XK - 1) / XK * XK;
+#else
     const int nk = (a.Cn + XK - 1) / XK, Cnp = nk * XK;
+#endif
     const int Rp = (a.R + 31) / 32 * 32;
     // weight fragments: rows past Rp fall off the end of the planes and read 0 (rows R .. Rp-1 are stored as zeros)
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)Rp * (unsigned)Cnp * (2u * NP));
@@ -496,7 +529,11 @@ void pw_gemm_b3p_kernel(PwArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
+#ifdef CTN_EXP_B3_NOA
+                for (int p = 0; p < NP; ++p) { float4 z = make_float4((float)lane, 1.f, 2.f, (float)kt); fa[i][ks][p] = __builtin_bit_cast(bf16x8, z); }
+#else
                 for (int p = 0; p < NP; ++p) fa[i][ks][p] = buf_ld_frag(rsW, voA[i] + kt * (2 * NP * 1024), (ks * NP + p) * 1024);
+#endif
     };
     auto load_b = [&](int kt, float4 (&rb)[B_L], float2 (&rp)[B_L], float4 (&ry)[B_L]) {
 #pragma unroll
@@ -527,7 +564,12 @@ void pw_gemm_b3p_kernel(PwArgs a) {
                 v.w = gln_bwd_elem(v.w, ry[j].w, rg, gq, c0 + k + 3 < a.K, dal);
             }
             bf16x4 q[NP];
+#ifdef CTN_EXP_B3_NOSPLIT
+            q[0] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            for (int p = 1; p < NP; ++p) q[p] = q[0];
+#else
             split_x4<NP>(v, q);
+#endif
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(S + (p * XK + i) * PB + k) = q[p];
         }
@@ -549,11 +591,25 @@ void pw_gemm_b3p_kernel(PwArgs a) {
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
+#ifdef CTN_EXP_B3_NOLDSRD
+                for (int p = 0; p < NP; ++p) { float4 z = make_float4((float)lane, 1.f, (float)stage, (float)ks); bfr[j][p] = __builtin_bit_cast(bf16x8, z); }
+#else
                 for (int p = 0; p < NP; ++p) bfr[j][p] = frag_tr(S + (p * XK + ks * 16) * PB + j * 32, PB, lane);
+#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) mfma_pieces<NP>(acc[i][j], fa[i][ks], bfr[j]);
+                for (int j = 0; j < NTL; ++j) {
+#ifdef CTN_EXP_B3_NOMFMA
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {          // keep every fragment live: one VALU op per fragment register instead of the MFMAs
+                        const float4 x = __builtin_bit_cast(float4, fa[i][ks][p]), y = __builtin_bit_cast(float4, bfr[j][p]);
+                        acc[i][j][p] += x.x * y.x; acc[i][j][p + 4] += x.y * y.y; acc[i][j][p + 8] += x.z * y.z; acc[i][j][p + 12] += x.w * y.w;
+                    }
+#else
+                    mfma_pieces<NP>(acc[i][j], fa[i][ks], bfr[j]);
+#endif
+                }
         }
     };
 
@@ -567,6 +623,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     store_b(0, rb, rp, ry);
     if (nk > 1) { load_a(1, fa1); load_b(1, rb, rp, ry); }
     __syncthreads();
+    CTN_TL_STAMP(1);
     for (int kt = 0; kt < nk; kt += 2) {
         compute(0, fa0);
         if (kt + 1 < nk) store_b(1, rb, rp, ry);
@@ -579,7 +636,13 @@ void pw_gemm_b3p_kernel(PwArgs a) {
             if (kt + 3 < nk) { load_a(kt + 3, fa1); load_b(kt + 3, rb, rp, ry); }
         }
     }
+    CTN_TL_STAMP(2);
+#ifdef CTN_EXP_B3_NOEPI
+    if (a.K < 0) a.Out[tid] = acc[0][0][0] + acc[MT - 1][NTL - 1][15];      // never taken: keeps the accumulators live
+#else
     gemm_epilogue<TL, EPI>(a, acc, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
+#endif
+    CTN_TL_STAMP(3);
 }
 
 // W fp32 -> fragment-ordered bf16 pieces (layout above).  value(r, k) = W[r * sr + k * sk]: (sr, sk) = (Cn, 1) for a stored
@@ -647,23 +710,31 @@ void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool 
 static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step (b3) 11.56 / 11.20 / 11.50 ms
 static int g_ctn_b3_wgrad_blocks = 256;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
-static void ctn_b3_tile_dims(int* tm, int* tn) {
+static int g_ctn_b3_tile_k3 = 2;            // tile of the K3 form (operand prologue + residual on pre-split weights, <= 256 rows): 256x64 =
+                                            // one workgroup per column tile, so the PReLU+gLN prologue and the split of the activation tile run
+                                            // once instead of once per 128-row tile (b6, alone: 45 vs 54 us); ctn_tune("b3_tile_k3", id)
+static void ctn_b3_tile_dims(int* tm, int* tn) {    // the tile of every form that writes statistics partials (their count is part of the ABI)
     static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
     *tm = d[g_ctn_b3_tile][0];
     *tn = d[g_ctn_b3_tile][1];
 }
+// tile id of one launch: forms without a statistics epilogue may pick their own
+static int ctn_b3_pick_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool gln_bwd) {
+    if (trans_w == 2 && pro && residual && !stats && !gln_bwd && a.R <= 256 && a.R > 128) return g_ctn_b3_tile_k3;
+    return g_ctn_b3_tile;
+}
 
 template <int NP>
-static void ctn_b3_launch_fwd_np(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     if (trans_w == 2) {             // a.W = fragment-ordered pieces (ctn_split_b3_batch)
-        switch (g_ctn_b3_tile) {
+        switch (tile) {
             case 1: launch_b3p_tile<NP, Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
             case 2: launch_b3p_tile<NP, Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
             default: launch_b3p_tile<NP, Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
         }
         return;
     }
-    switch (g_ctn_b3_tile) {
+    switch (tile) {
         case 1: launch_b3_tile<NP, T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         case 2: launch_b3_tile<NP, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         default: launch_b3_tile<NP, T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
@@ -671,12 +742,12 @@ static void ctn_b3_launch_fwd_np(PwArgs& a, int trans_w, bool pro, bool residual
 }
 
 static void ctn_b3_launch_fwd(int np, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
-    int tm, tn;
-    ctn_b3_tile_dims(&tm, &tn);
-    a.tiles_r = ctn_cdiv(a.R, tm);
-    a.tiles_c = ctn_cdiv(a.Kp, tn);
-    if (np == 3) ctn_b3_launch_fwd_np<3>(a, trans_w, pro, residual, stats, relu, gln_bwd, st);
-    else ctn_b3_launch_fwd_np<2>(a, trans_w, pro, residual, stats, relu, gln_bwd, st);
+    static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
+    const int tile = ctn_b3_pick_tile(a, trans_w, pro, residual, stats, gln_bwd);
+    a.tiles_r = ctn_cdiv(a.R, d[tile][0]);
+    a.tiles_c = ctn_cdiv(a.Kp, d[tile][1]);
+    if (np == 3) ctn_b3_launch_fwd_np<3>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
+    else ctn_b3_launch_fwd_np<2>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
 }
 
 static size_t ctn_b3_planes_bytes(int np, int R, int Cn) {
