@@ -1,4 +1,4 @@
-# usage (GPU box): bash benchmarks/power_lab.sh [mfma]  -> gpurun_out/r02_power_lab[_mfma].txt  (W, us and mJ per launch per case)
+# usage (GPU box): bash benchmarks/power_lab.sh mfma|step  -> gpurun_out/r02_power_lab[_mfma].txt  (W, us and mJ per launch per case)
 # the sampler runs in a shell loop started BEFORE the measured process touches the GPU
 mkdir -p gpurun_out
 MODE=${1:-kernels}
@@ -6,11 +6,7 @@ MODE=${1:-kernels}
 SP=$!
 if [ "$MODE" = mfma ]; then ./benchmarks/mfma_probe.bin 5 > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
 elif [ "$MODE" = step ]; then python benchmarks/power_lab_step.py > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
-elif [ "$MODE" = x ]; then      # split-bf16 experiments: three libraries, one process each (per-kernel sequencing for all three)
-  LABEL=f32 CTN_COMPOSITE=0 python benchmarks/power_lab_x.py > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
-  LABEL=x6 CTN_COMPOSITE=0 CTN_EXPERIMENTAL=1 CTN_LIB_PATH=benchmarks/lab_x6.so python benchmarks/power_lab_x.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err
-  LABEL=x3 CTN_COMPOSITE=0 CTN_EXPERIMENTAL=1 CTN_LIB_PATH=benchmarks/lab_x3.so python benchmarks/power_lab_x.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err
-else python benchmarks/power_lab.py > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err; fi
+else echo "usage: power_lab.sh mfma|step   (per-kernel energies: benchmarks/power_lab_b6.sh)"; kill $SP; exit 1; fi
 kill $SP
 export MODE
 python - <<'PY'
@@ -20,7 +16,7 @@ for l in open("gpurun_out/power_samples.txt"):
     if len(p) == 2:
         samples.append((float(p[0]), float(p[1])))
 import os
-out = open("gpurun_out/r02_power_lab%s.txt" % {"mfma": "_mfma", "x": "_x", "step": "_step"}.get(os.environ.get("MODE"), ""), "w")
+out = open("gpurun_out/power_lab%s.txt" % {"mfma": "_mfma", "x": "_x", "step": "_step"}.get(os.environ.get("MODE"), ""), "w")
 for l in open("gpurun_out/power_cases.txt"):
     p = l.split()
     if p and p[0] == "case":

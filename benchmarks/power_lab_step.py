@@ -40,6 +40,6 @@ def case(name, fn):
 
 
 case("idle", lambda: time.sleep(0.01))
-for arith in ("b3", "fp32", "b3"):
+for arith in ("b6", "fp32", "b3", "b6"):
     ctn.set_gemm_arith(arith)
     case("training_step_" + arith, step)

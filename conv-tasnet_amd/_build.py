@@ -9,9 +9,6 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libctn_hip.so")
 SOURCES = ["ctn_api.hip", "ctn_gemm.hip", "ctn_tcn.hip", "ctn_bn.hip", "ctn_codec.hip", "ctn_loss.hip", "ctn_optim.hip",
            "ctn_block.hip"]
-# opt-in experiment (split-bf16 GEMMs, include/ctn_hip_experimental.h): CTN_BUILD_X6=1
-if os.environ.get("CTN_BUILD_X6") == "1":
-    SOURCES.append(os.path.join("experimental", "ctn_gemm_x6.hip"))
 # -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs (unified file on gfx950), so the epilogues read them without
 # v_accvgpr_read copies -- every VALU instruction serialises with the fp32 MFMAs (profiles/r02_a_mfma_probe.txt)
 # -fno-slp-vectorize: keeps the compiler from packing adjacent scalar f32 adds / subs into v_pk_add_f32, which costs more

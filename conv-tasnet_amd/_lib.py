@@ -8,11 +8,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ctn_hip.h")
-HEADER_EXPERIMENTAL = os.path.join(os.path.dirname(_HERE), "include", "ctn_hip_experimental.h")
-# CTN_LIB_PATH: an alternative build of the same ABI (benchmarks/gemm_lab.py compares experiment builds)
+# CTN_LIB_PATH: an alternative build of the same ABI (benchmarks/b3_lab_build.sh: phase-ablation builds)
 LIB_PATH = os.environ.get("CTN_LIB_PATH") or os.path.join(_HERE, "libctn_hip.so")
-# CTN_EXPERIMENTAL=1 also binds include/ctn_hip_experimental.h (needs a library built with CTN_BUILD_X6=1)
-EXPERIMENTAL = os.environ.get("CTN_EXPERIMENTAL") == "1"
 
 _SCALARS = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float,
             "size_t": ctypes.c_size_t, "double": ctypes.c_double}
@@ -54,8 +51,6 @@ class _Lib:
         self._dll = None
         self.probe = None       # list -> every lib.call is bracketed by two timing events (bench.py's roofline leg)
         self.protos = parse_header()
-        if EXPERIMENTAL:
-            self.protos.update(parse_header(HEADER_EXPERIMENTAL))
 
     def load(self):
         if self._dll is None:

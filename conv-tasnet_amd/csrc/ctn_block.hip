@@ -14,11 +14,6 @@
 #include "../../include/ctn_hip.h"
 #include <vector>
 
-extern "C" int ctn_pw_uses_pk(void);       // ctn_gemm.hip
-int g_ctn_block_fuse_b4 = 0;             // ctn_tune("fuse_b4", 1): gln_prelu_bwd folded into its two consumers (b3): bitwise the
-                                         // same gradients, measured 10.23 vs 10.13 ms per step -> off by default
-int g_ctn_block_fin_side = 1;            // ctn_tune("fin_side", 0): parameter-gradient sums on the chain's stream (A/B runs)
-int g_ctn_block_wt = 1;                     // ctn_tune("block_wt", 0): forward GEMMs on the stored [O, I] weights (A/B runs)
 
 // ---- measurement hook (bench.py's roofline leg): HIP events around every launch group of the composite stacks, on the stream
 // the group is launched to.  Off by default (no events, no overhead); ctn_probe_enable(1) starts a recording, ctn_probe_read
@@ -143,10 +138,7 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.s1p = o; o += (size_t)nblocks * w.s1p_slot;
     // per-block slots: the finalize kernel of block i runs on the weight-gradient stream while the chain is already in block i-1
     w.pc_slot = align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
-    {   // PReLU-slope partials: M*H from ctn_gln_prelu_bwd, or one per (slab, row tile) from the fused weight gradient
-        const size_t n_unfused = (size_t)M * H, n_fused = (size_t)ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp);
-        w.da1p_slot = align256((n_unfused > n_fused ? n_unfused : n_fused) * sizeof(float));
-    }
+    w.da1p_slot = align256((size_t)M * H * sizeof(float));          // PReLU-slope partials of ctn_gln_prelu_bwd: one per (m, channel)
     w.pc = o; o += (size_t)nblocks * w.pc_slot;
     w.da1p = o; o += (size_t)nblocks * w.da1p_slot;
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
@@ -182,13 +174,12 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     // [I, O] fp32 copies (16-byte LDS row writes instead of the transposing scatter); two launches for the whole stack
     char* const wreg = (char*)workspace + w.wt;
     const size_t slot = wslot_bytes(B, H);
-    const bool use_wt = g_ctn_block_wt != 0;
     int tw1 = 0, tw2 = 0;
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
     }
-    if (use_wt) {
+    {
         int rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream);
         if (rc) return rc;
     }
@@ -196,8 +187,8 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
-        const float* const w1t = use_wt ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W1];
-        const float* const w2t = use_wt ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W2];
+        const float* const w1t = (const float*)(wreg + (size_t)(2 * i) * slot);
+        const float* const w2t = (const float*)(wreg + (size_t)(2 * i + 1) * slot);
         // save = 0 (inference): one h1 / d slot and two ping-pong x slots; save = 1: a slot per block for the backward pass
         float* const h1 = h1s + (save ? (size_t)i * hsz : 0);
         float* const d = ds + (save ? (size_t)i * hsz : 0);
@@ -271,35 +262,26 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
                         p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream));
         if (rc) return rc;
-        // gLN1' / PReLU1' backward: its own pass (B4), or -- opt-in, b3 arithmetic -- folded into the prologues of its two
-        // consumers (dn1 stays the raw gradient; the 157 MB pass and its launch leave the chain, the two GEMMs read h1 too)
-        const bool fused = g_ctn_block_fuse_b4 && twb == 2 && ctn_gemm_arith() != 0 && H >= 32 && B >= 32;
-        int n_da1 = M * H;
-        if (!fused) {
-            rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream));
-            if (rc) return rc;
-        } else {
-            n_da1 = ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp);
-        }
+        // gLN1' / PReLU1' backward in place (B4).  (Folding it into the operand prologues of its two consumers was built and
+        // measured in round 2: 10.23 vs 10.13 ms per step with B4 as its own pass -- both GEMMs then read h1 as well.)
+        const int n_da1 = M * H;
+        rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream));
+        if (rc) return rc;
         // first 1x1; the weight gradient and the fixed-order sums of this block's parameter-gradient partials feed only the
         // optimiser: second stream
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         auto wgrad1 = [&]() -> int {
-            if (fused) return PROBED(F_B6, wst, ctn_pw_wgrad_glnbwd(dn1, h1, x, g[P_W1], M, H, B, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, da1p, slab, w.slab_bytes, wst));
             return PROBED(F_B6, wst, ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
         };
         auto finalize = [&](void* st) -> int {
             return PROBED(F_FIN, st, ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st));
         };
-        if (side_stream) {          // (the fused weight gradient produces the PReLU-slope partials: finalize after it)
+        if (side_stream) {          // the fixed-order sums feed only the optimiser: second stream, behind the weight gradient
             if ((rc = wgrad1())) return rc;
-            if ((rc = finalize(g_ctn_block_fin_side || fused ? wst : stream))) return rc;
+            if ((rc = finalize(wst))) return rc;
         }
-        if (fused)
-            rc = PROBED(F_B5, stream, ctn_pw_gemm_glnbwd(wreg + (size_t)(2 * i + 1) * slot, dn1, h1, dx, M, B, H, K, Kp, s1p, H, p[P_G1], p[P_A1], ms1, dy, stream));
-        else
-            rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
-                             nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
+        rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                         nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
         if (rc) return rc;
         if (!side_stream) {
             if ((rc = wgrad1())) return rc;
@@ -437,7 +419,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, stream)))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         // the three fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
-        void* const fst = g_ctn_block_fin_side ? wst : stream;
+        void* const fst = wst;
         if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
         if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
         if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst)))) return rc;

@@ -257,11 +257,8 @@ void pw_gemm_b3_kernel(PwArgs a) {
 // fp32 slabs summed in fixed order by slab_reduce_kernel.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WNT = 512;
-// APRO: gLN'/PReLU' backward applied on the fly to the dOut operand (the B4 pass of DESIGN.md folded into this kernel and
-// into the input-gradient GEMM: dOut stays the raw gradient with respect to the norm's output); the workgroups of column
-// tile 0 also sum the PReLU-slope gradient of their rows and frames.
-template <int NP, int PRO, int APRO>
-__global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a) {
+template <int NP, int PRO>
+__global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     constexpr int PLANE = BM * XPA, STAGE = NP * PLANE;       // bf16 elements: one piece plane, all pieces of one operand
     __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * STAGE];          // [stage][piece][BM][XPA]   (NP = 3: 2 x 60 KiB)
     __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * STAGE];
@@ -282,16 +279,6 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
     const float* __restrict__ Gm = a.dOut + (size_t)m * a.R * a.Kp;
     const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
 
-    GlnBwdQ gq{};
-    float rgA[2] = {0.f, 0.f}, dal = 0.f;
-    if constexpr (APRO) {
-        gq = gln_bwd_uniform<WNT>(a.a_part, a.a_nparts, m, (double)a.R * (double)a.K, a.a_ms, a.a_alpha, red);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = r0 + (tid >> 3) + 64 * j;
-            rgA[j] = r < a.R ? gq.rstd * a.a_gamma[r] : 0.f;
-        }
-    }
     float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
     if constexpr (PRO == PRO_PRELU_NORM) {
         p_mean = a.pro_ms[2 * m];
@@ -302,9 +289,8 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
     // fall off the end of the utterance's matrix and read 0; frames past the chunk end are pushed out of range.
     const __amdgpu_buffer_rsrc_t rsG = make_rsrc(Gm, (unsigned)a.R * (unsigned)a.Kp * 4u);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
-    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(APRO ? a.a_y + (size_t)m * a.R * a.Kp : Gm, (unsigned)a.R * (unsigned)a.Kp * 4u);
     constexpr int PF = 3;           // k-tiles of global loads in flight (register ring)
-    float4 ra[PF][2], rb[PF][2], ry[PF][2];
+    float4 ra[PF][2], rb[PF][2];
     float2 rg[2];
     if constexpr (PRO == PRO_PRELU_NORM) {
 #pragma unroll
@@ -315,14 +301,13 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
     }
     const int nk = (ke - kb + XK - 1) / XK;
     const int kq = (tid & 7) * 4;
-    auto load_regs = [&](int kt, float4 (&qa)[2], float4 (&qb)[2], float4 (&qy)[2]) {
+    auto load_regs = [&](int kt, float4 (&qa)[2], float4 (&qb)[2]) {
         const int k = kb + kt * XK + kq;
         const unsigned oob = k < ke ? 0u : 0x80000000u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (tid >> 3) + 64 * j;
             qa[j] = buf_ld4(rsG, (int)((unsigned)(((r0 + row) * a.Kp + k) * 4) + oob), 0);
-            if constexpr (APRO) qy[j] = buf_ld4(rsY, (int)((unsigned)(((r0 + row) * a.Kp + k) * 4) + oob), 0);
             qb[j] = buf_ld4(rsX, (int)((unsigned)(((c0 + row) * a.Kp + k) * 4) + oob), 0);
         }
     };
@@ -332,21 +317,11 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(P + p * PLANE + row * XPA + kq) = q[p];
     };
-    auto write_lds = [&](int kt, int stage, const float4 (&qa)[2], const float4 (&qb)[2], const float4 (&qy)[2]) {
+    auto write_lds = [&](int kt, int stage, const float4 (&qa)[2], const float4 (&qb)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (tid >> 3) + 64 * j;
-            float4 g = qa[j];
-            if constexpr (APRO) {       // (frames past the chunk end read dN = y = 0 and are frames >= K: result 0, no slope term)
-                const int kf = kb + kt * XK + kq;
-                float d = 0.f;
-                g.x = gln_bwd_elem(g.x, qy[j].x, rgA[j], gq, kf + 0 < a.K, d);
-                g.y = gln_bwd_elem(g.y, qy[j].y, rgA[j], gq, kf + 1 < a.K, d);
-                g.z = gln_bwd_elem(g.z, qy[j].z, rgA[j], gq, kf + 2 < a.K, d);
-                g.w = gln_bwd_elem(g.w, qy[j].w, rgA[j], gq, kf + 3 < a.K, d);
-                if (ct == 0 && r0 + row < a.R) dal += d;
-            }
-            write_one(Ap + stage * STAGE, row, g);
+            write_one(Ap + stage * STAGE, row, qa[j]);
             float4 x = qb[j];
             // (frames past the chunk end are frames >= Kp >= K: the prologue zeroes them like every frame >= K)
             if constexpr (PRO == PRO_PRELU_NORM) x = pro_apply(x, kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
@@ -382,11 +357,14 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
     // % PF hold tiles kt + 1 .. in flight or landed.  One workgroup per CU (256 workgroups, the measured optimum in the step)
     // has no other workgroup to hide the load latency behind: distance 1 left ~1 us of every 1.4 us k-tile waiting.
     // Unrolled by 6: ring slot and stage indices are compile-time constants.
+    // (Round 3, b6: running the two halves of each barrier interval -- MFMAs of tile kt, split of tile kt + 1 -- in opposite
+    // order on waves 4-7, so that each wave's VALU half sits beside its SIMD partner's MFMA half, measured SLOWER: 48.7 vs
+    // 44.9 us alone, 13.71 vs 13.43 ms per step; profiles/README.md.)
     if (nk > 0) {
-        load_regs(0, ra[0], rb[0], ry[0]);
-        if (nk > 1) load_regs(1, ra[1], rb[1], ry[1]);
-        if (nk > 2) load_regs(2, ra[2], rb[2], ry[2]);
-        write_lds(0, 0, ra[0], rb[0], ry[0]);
+        load_regs(0, ra[0], rb[0]);
+        if (nk > 1) load_regs(1, ra[1], rb[1]);
+        if (nk > 2) load_regs(2, ra[2], rb[2]);
+        write_lds(0, 0, ra[0], rb[0]);
         __syncthreads();
     }
     for (int kt0 = 0; kt0 < nk; kt0 += 6) {
@@ -394,16 +372,12 @@ __global__ __launch_bounds__(WNT, APRO ? 1 : 2) void pw_wgrad_b3_kernel(WgArgs a
         for (int u = 0; u < 6; ++u) {
             const int kt = kt0 + u;
             if (kt < nk) {
-                if (kt + PF < nk) load_regs(kt + PF, ra[u % PF], rb[u % PF], ry[u % PF]);          // slot of tile kt: already in LDS
+                if (kt + PF < nk) load_regs(kt + PF, ra[u % PF], rb[u % PF]);          // slot of tile kt: already in LDS
                 compute(u % 2);
-                if (kt + 1 < nk) write_lds(kt + 1, (u + 1) % 2, ra[(u + 1) % PF], rb[(u + 1) % PF], ry[(u + 1) % PF]);
+                if (kt + 1 < nk) write_lds(kt + 1, (u + 1) % 2, ra[(u + 1) % PF], rb[(u + 1) % PF]);
                 __syncthreads();
             }
         }
-    }
-    if constexpr (APRO) {           // PReLU-slope gradient of this workgroup's rows and frames (column tile 0 only), fixed order
-        const double dsum = block_sum<double, WNT>((double)dal, red);
-        if (ct == 0 && tid == 0) a.dalpha_part[(size_t)sp * a.tiles_r + rt] = (float)dsum;
     }
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
@@ -484,8 +458,6 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     const float* __restrict__ Xm = a.X + (size_t)m * a.Cn * a.Kp;
 
     float p_mean = 0.f, p_rstd = 1.f, p_alpha = 0.f;
-    GlnBwdQ gq{};
-    if constexpr (PRO == PRO_GLN_BWD) gq = gln_bwd_uniform<NTH>(a.pro_part, a.pro_nparts, m, (double)a.Cn * (double)a.K, a.pro_ms, a.pro_alpha, red);
     if constexpr (PRO == PRO_PRELU_NORM) {
         finalize_stats<NTH>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts, (double)a.Cn * (double)a.K, red, p_mean, p_rstd);
         p_alpha = a.pro_alpha[0];
@@ -503,14 +475,10 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     // weight fragments: rows past Rp fall off the end of the planes and read 0 (rows R .. Rp-1 are stored as zeros)
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)Rp * (unsigned)Cnp * (2u * NP));
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
-    __amdgpu_buffer_rsrc_t rsG = rsX, rsBt = rsX, rsY = rsX;
+    __amdgpu_buffer_rsrc_t rsG = rsX, rsBt = rsX;
     if constexpr (PRO == PRO_PRELU_NORM) {
         rsG = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
         rsBt = make_rsrc(a.pro_beta, (unsigned)a.Cn * 4u);
-    }
-    if constexpr (PRO == PRO_GLN_BWD) {
-        rsG = make_rsrc(a.pro_gamma, (unsigned)a.Cn * 4u);
-        rsY = make_rsrc(a.pro_y + (size_t)m * a.Cn * a.Kp, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
     }
     int voA[MT], voB[B_L], voP[B_L];
 #pragma unroll
@@ -535,34 +503,23 @@ void pw_gemm_b3p_kernel(PwArgs a) {
                 for (int p = 0; p < NP; ++p) fa[i][ks][p] = buf_ld_frag(rsW, voA[i] + kt * (2 * NP * 1024), (ks * NP + p) * 1024);
 #endif
     };
-    auto load_b = [&](int kt, float4 (&rb)[B_L], float2 (&rp)[B_L], float4 (&ry)[B_L]) {
+    auto load_b = [&](int kt, float4 (&rb)[B_L], float2 (&rp)[B_L]) {
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
             rb[j] = buf_ld4(rsX, voB[j] + kt * sB, 0);
             if constexpr (PRO == PRO_PRELU_NORM)
                 rp[j] = make_float2(buf_ld1(rsG, voP[j] + kt * XK * 4, 0), buf_ld1(rsBt, voP[j] + kt * XK * 4, 0));
-            else if constexpr (PRO == PRO_GLN_BWD) {
-                rp[j] = make_float2(buf_ld1(rsG, voP[j] + kt * XK * 4, 0), 0.f);
-                ry[j] = buf_ld4(rsY, voB[j] + kt * sB, 0);
-            } else
+            else
                 rp[j] = make_float2(0.f, 0.f);
         }
     };
-    auto store_b = [&](int stage, const float4 (&rb)[B_L], const float2 (&rp)[B_L], const float4 (&ry)[B_L]) {
+    auto store_b = [&](int stage, const float4 (&rb)[B_L], const float2 (&rp)[B_L]) {
         __bf16* const S = Bp + stage * L::STAGE_ELEMS;
 #pragma unroll
         for (int j = 0; j < B_L; ++j) {
             const int i = tid / (TN / 4) + (4 * NTH / TN) * j, k = (tid % (TN / 4)) * 4;
             float4 v = rb[j];
             if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
-            if constexpr (PRO == PRO_GLN_BWD) {
-                const float rg = gq.rstd * rp[j].x;
-                float dal = 0.f;        // (the PReLU-slope gradient is collected by the weight-gradient kernel)
-                v.x = gln_bwd_elem(v.x, ry[j].x, rg, gq, c0 + k + 0 < a.K, dal);
-                v.y = gln_bwd_elem(v.y, ry[j].y, rg, gq, c0 + k + 1 < a.K, dal);
-                v.z = gln_bwd_elem(v.z, ry[j].z, rg, gq, c0 + k + 2 < a.K, dal);
-                v.w = gln_bwd_elem(v.w, ry[j].w, rg, gq, c0 + k + 3 < a.K, dal);
-            }
             bf16x4 q[NP];
 #ifdef CTN_EXP_B3_NOSPLIT
             q[0] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -616,24 +573,24 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     // k-tile kt: weight fragments in one register set, activation tile in LDS stage kt & 1; while it is multiplied, tile
     // kt + 1 (already in registers) is split into the other stage and the loads of tile kt + 2 are issued.
     bf16x8 fa0[MT][2][NP], fa1[MT][2][NP];
-    float4 rb[B_L], ry[B_L];
+    float4 rb[B_L];
     float2 rp[B_L];
     load_a(0, fa0);
-    load_b(0, rb, rp, ry);
-    store_b(0, rb, rp, ry);
-    if (nk > 1) { load_a(1, fa1); load_b(1, rb, rp, ry); }
+    load_b(0, rb, rp);
+    store_b(0, rb, rp);
+    if (nk > 1) { load_a(1, fa1); load_b(1, rb, rp); }
     __syncthreads();
     CTN_TL_STAMP(1);
     for (int kt = 0; kt < nk; kt += 2) {
         compute(0, fa0);
-        if (kt + 1 < nk) store_b(1, rb, rp, ry);
+        if (kt + 1 < nk) store_b(1, rb, rp);
         __syncthreads();
-        if (kt + 2 < nk) { load_a(kt + 2, fa0); load_b(kt + 2, rb, rp, ry); }
+        if (kt + 2 < nk) { load_a(kt + 2, fa0); load_b(kt + 2, rb, rp); }
         if (kt + 1 < nk) {
             compute(1, fa1);
-            if (kt + 2 < nk) store_b(0, rb, rp, ry);
+            if (kt + 2 < nk) store_b(0, rb, rp);
             __syncthreads();
-            if (kt + 3 < nk) { load_a(kt + 3, fa1); load_b(kt + 3, rb, rp, ry); }
+            if (kt + 3 < nk) { load_a(kt + 3, fa1); load_b(kt + 3, rb, rp); }
         }
     }
     CTN_TL_STAMP(2);
@@ -676,7 +633,6 @@ template <int NP, typename TL>
 void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
-    else if (a.pro_y != nullptr) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_GLN_BWD, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
     else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
@@ -785,9 +741,8 @@ static void ctn_b3_wgrad_plan(int M, int R, int Cn, int Kp, int* chunk, int* chu
 template <int NP>
 static void ctn_b3_launch_wgrad_np(const WgArgs& a, bool pro, dim3 grid, hipStream_t st) {
     const dim3 block(WNT);
-    if (a.a_y != nullptr) hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_NONE, 1>), grid, block, 0, st, a);      // (the dW1 form: no X prologue)
-    else if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_PRELU_NORM, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_NONE, 0>), grid, block, 0, st, a);
+    if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_PRELU_NORM>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_NONE>), grid, block, 0, st, a);
 }
 
 // a.chunk / a.chunks_per_m / a.slab already set by the caller from ctn_b3_wgrad_plan; returns the number of slabs

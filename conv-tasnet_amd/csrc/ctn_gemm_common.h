@@ -1,5 +1,5 @@
-// Shared device / host pieces of the 1x1-convolution GEMM translation units (fp32-MFMA product kernels in
-// ctn_gemm.hip; the opt-in split-bf16 experiment in experimental/ctn_gemm_x6.hip).  gfx950 only.
+// Shared device / host pieces of the 1x1-convolution GEMM kernels (fp32-MFMA kernels in ctn_gemm.hip, split-bf16
+// kernels in ctn_gemm_b3.h).  gfx950 only.
 #pragma once
 #include "ctn_common.h"
 #include <stdlib.h>
@@ -13,7 +13,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
 
-enum { PRO_NONE = 0, PRO_PRELU_NORM = 1, PRO_GLN_BWD = 2 };
+enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
 enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4 };
 
 // Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
@@ -44,14 +44,6 @@ using T128x128 = Tile<128, 128, 2, 2>;
 using T128x64 = Tile<128, 64, 2, 2>;
 using T64x128 = Tile<64, 128, 2, 2>;
 using T64x64 = Tile<64, 64, 2, 2>;
-using T64x64m16 = Tile<64, 64, 2, 2, 16, 16>;     // the same tile on v_mfma_f32_16x16x4_f32
-using T128x64w = Tile<128, 64, 4, 1>;
-using T64x64k32 = Tile<64, 64, 2, 2, 32>;
-using T128x64k32 = Tile<128, 64, 2, 2, 32>;
-using T128x128k32 = Tile<128, 128, 2, 2, 32>;
-using T128x128w8 = Tile<128, 128, 2, 4>;      // 8 waves, each 64x32 (split-bf16 kernels only)
-using T128x64w8 = Tile<128, 64, 4, 2>;        // 8 waves, each 32x32
-using T128x64w8k32 = Tile<128, 64, 4, 2, 32>; // the fp32 kernel needs a 32-deep k-tile to give 512 threads a float4 each
 
 struct PwArgs {
     const float* W;      // TRANS_W=0: [R, Cn]   TRANS_W=1: [Cn, R]
@@ -63,20 +55,11 @@ struct PwArgs {
     const double* pro_part; int pro_nparts;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha;
     float* pro_ms_out;   // [M,2] (mean, rstd) for the backward pass, optional
-    // PRO_GLN_BWD (b3 kernel on pre-split weights): the operand is gLN'/PReLU' applied on the fly to X = dN (gradient with
-    // respect to the norm's output):  x' = rstd*(gamma[i]*dN - S1/n - xh*S2/n) * prelu'(y),  xh = (prelu(y) - mean)*rstd,
-    // y = pro_y [M,Cn,Kp] the norm's pre-activation input, (mean, rstd) = pro_ms [M,2], (S1, S2) = sums of the
-    // [M, pro_nparts, 2] fp64 partials in pro_part, n = Cn*K; pro_gamma, pro_alpha as above.  0 for frames k >= K.
-    const float* pro_y; const float* pro_ms;
     // epilogues
     const float* residual;                         // EPI_RESIDUAL: [M,R,Kp]
     const float* epi_alpha; double* epi_part;      // EPI_PRELU_STATS: [M, tiles_r*tiles_c, 2]
     const float* bwd_y; const float* bwd_gamma; const float* bwd_alpha;
     const float* bwd_ms; double* bwd_part;         // EPI_GLN_BWD
-    // split-bf16 pipeline: optional per-(m,row) bias added for k < K, and the result also emitted as three bf16 planes
-    const float* row_bias;                         // [M, R] or NULL
-    void* out_planes; size_t out_plane_stride;     // [3][M,R,Kp] bf16 or NULL; stride between planes in elements
-    int store_f32;                                 // 0: skip the fp32 store (planes only)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -124,63 +107,16 @@ __device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, flo
     return v;
 }
 
-// gLN'/PReLU' backward of one element (the arithmetic of gln_prelu_bwd_kernel, ctn_tcn.hip, bit for bit):
-//   q = {rstd, alpha*rstd, mean*rstd, rstd*S1/n, rstd*S2/n, alpha};  rg = rstd*gamma[channel];  returns dY, adds to dal
-struct GlnBwdQ { float rstd, ar, mr, rc1, rc2, al; };
-__device__ __forceinline__ float gln_bwd_elem(float dn, float y, float rg, const GlnBwdQ& q, bool valid, float& dal) {
-    const float xh = fmaf(y, y >= 0.f ? q.rstd : q.ar, -q.mr);
-    const float da = fmaf(-xh, q.rc2, fmaf(rg, dn, -q.rc1));
-    if (valid && y < 0.f) dal += da * y;
-    return valid ? (y >= 0.f ? da : q.al * da) : 0.f;
-}
-// the uniform part: sums of the fp64 partials of utterance m (fixed order), every thread of the block gets the same values
-template <int NTH>
-__device__ __forceinline__ GlnBwdQ gln_bwd_uniform(const double* __restrict__ part, int nparts, int m, double count,
-                                                   const float* __restrict__ ms, const float* __restrict__ alpha, double* red) {
-    double S1 = 0.0, S2 = 0.0;
-    if (threadIdx.x < 256)              // 256 strided partial sums whatever the block size: the bits of gln_prelu_bwd_kernel
-        for (int i = threadIdx.x; i < nparts; i += 256) {
-            S1 += part[((size_t)m * nparts + i) * 2];
-            S2 += part[((size_t)m * nparts + i) * 2 + 1];
-        }
-    S1 = block_sum<double, NTH>(S1, red);
-    S2 = block_sum<double, NTH>(S2, red);
-    const float c1 = (float)(S1 / count), c2 = (float)(S2 / count);
-    const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha[0];
-    return GlnBwdQ{rstd, al * rstd, mean * rstd, rstd * c1, rstd * c2, al};
-}
-
-// exact 3-way bf16 split of an fp32 value: v = a + b + c, 8 significand bits each
-struct Bf3 { __bf16 a, b, c; };
-__device__ __forceinline__ Bf3 split3(float v) {
-    Bf3 r;
-    r.a = (__bf16)v;
-    const float r1 = v - (float)r.a;
-    r.b = (__bf16)r1;
-    r.c = (__bf16)(r1 - (float)r.b);
-    return r;
-}
-// four consecutive fp32 -> the three bf16x4 pieces
-__device__ __forceinline__ void split3x4(const float4& v, bf16x4& q1, bf16x4& q2, bf16x4& q3) {
-    const Bf3 s0 = split3(v.x), s1 = split3(v.y), s2 = split3(v.z), s3 = split3(v.w);
-    q1 = bf16x4{s0.a, s1.a, s2.a, s3.a};
-    q2 = bf16x4{s0.b, s1.b, s2.b, s3.b};
-    q3 = bf16x4{s0.c, s1.c, s2.c, s3.c};
-}
-
-
 // ---- shared epilogue (fp32-MFMA and split-bf16 kernels: the 32x32 C/D register map is dtype-independent) ----
 // Each wave transposes its accumulators through a private LDS patch (32 rows at a time) so that global traffic
 // is 16 bytes per lane along frames instead of 64 dword accesses; residual / ReLU / PReLU-statistics / gLN-backward
 // sums are applied on the float4s.  C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-// NTHB: threads of the workgroup (>= TL::NTH); waves beyond TL::NW pass active = false, hold no accumulators and only
-// take part in the block-wide sums.  EXTRAS: per-row bias and bf16-plane output of the pre-split ("p6") kernels.
 // Global traffic goes through buffer descriptors of this utterance's [R, Kp] matrices: rows >= R are dropped /
 // read as 0 by the hardware range check (their accumulators are exact zeros, so the statistics need no row
 // predicate either); only a tile that overhangs Kp -- a uniform condition -- masks its columns per lane.
-template <typename TL, int EPI, int NTHB = TL::NTH, bool EXTRAS = false>
+template <typename TL, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL::MT][TL::NTL], float* smem, double* red,
-                                              int m, int rt, int ct, bool active = true) {
+                                              int m, int rt, int ct) {
     constexpr int MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, TM = TL::TM, TN = TL::TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / TL::WGN, wn = wave % TL::WGN;
@@ -200,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     float s1 = 0.f, s2 = 0.f;
     const size_t mbase = (size_t)m * a.R * a.Kp;
     const unsigned mat_bytes = (unsigned)a.R * (unsigned)a.Kp * 4u;
-    const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, a.store_f32 ? mat_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, mat_bytes);
     __amdgpu_buffer_rsrc_t rsAux = rsOut, rsGam = rsOut;
     if constexpr (EPI == EPI_RESIDUAL) rsAux = make_rsrc(a.residual + mbase, mat_bytes);
     if constexpr (EPI == EPI_GLN_BWD) {
@@ -211,7 +147,6 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     const int rl0 = lane / C4, cl = (lane % C4) * 4;
     const int kcol = c0 + wn * WN + cl;
     const int vo0 = ((r0 + wm * WM + rl0) * a.Kp + kcol) * 4;
-    if (active)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -255,33 +190,14 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     s1 += (t0 + t1) + (t2 + t3);
                     s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
                 }
-                if constexpr (EXTRAS) {
-                    const int r = r0 + wm * WM + mt * 32 + rl;
-                    if (a.row_bias != nullptr && r < a.R) {
-                        const float bia = a.row_bias[(size_t)m * a.R + r];
-                        v.x += (kcol + 0 < a.K) ? bia : 0.f; v.y += (kcol + 1 < a.K) ? bia : 0.f;
-                        v.z += (kcol + 2 < a.K) ? bia : 0.f; v.w += (kcol + 3 < a.K) ? bia : 0.f;
-                    }
-                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, f32x4v{v.x, v.y, v.z, v.w}), rsOut, vo0, so, 0);
-                if constexpr (EXTRAS) {
-                    const int r = r0 + wm * WM + mt * 32 + rl;
-                    if (a.out_planes != nullptr && r < a.R) {
-                        bf16x4 q1, q2, q3;
-                        split3x4(v, q1, q2, q3);
-                        __bf16* P = reinterpret_cast<__bf16*>(a.out_planes) + mbase + (size_t)r * a.Kp + kcol;
-                        *reinterpret_cast<bf16x4*>(P) = q1;
-                        *reinterpret_cast<bf16x4*>(P + a.out_plane_stride) = q2;
-                        *reinterpret_cast<bf16x4*>(P + 2 * a.out_plane_stride) = q3;
-                    }
-                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
-        const double d1 = block_sum<double, NTHB>((double)s1, red);
-        const double d2 = block_sum<double, NTHB>((double)s2, red);
+        const double d1 = block_sum<double, TL::NTH>((double)s1, red);
+        const double d2 = block_sum<double, TL::NTH>((double)s2, red);
         if (tid == 0) {
             double* dst = (EPI == EPI_PRELU_STATS ? a.epi_part : a.bwd_part) +
                           ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 2;
@@ -304,11 +220,6 @@ struct WgArgs {
     int M, R, Cn, K, Kp;
     int tiles_r, tiles_c, chunk, chunks_per_m;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
-    // b3 kernel: gLN'/PReLU' applied on the fly to the dOut operand (see PwArgs::pro_y): a_y [M,R,Kp], a_gamma [R], a_alpha [1],
-    // a_ms [M,2], a_part [M, a_nparts, 2] fp64; the workgroups of column tile 0 also emit the PReLU-slope gradient partials
-    // dalpha_part [nsplit * tiles_r] (a_y == NULL: plain dOut)
-    const float* a_y; const float* a_gamma; const float* a_alpha; const float* a_ms; const double* a_part; int a_nparts;
-    float* dalpha_part;
 };
 
 
@@ -349,15 +260,12 @@ int check_common(const char* fn, const float* W, const float* X, const float* Ou
 
 }  // namespace
 
-// ---- tile selection (shared by the fp32 and the experimental launchers; ctn_tune_pw_tile sets the override) ----
-// id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64, 4 = 128x64 (4x1 waves), 5..7 = 64x64 / 128x64 / 128x128 with BK = 32,
-//     8 / 9 = 128x128 / 128x64 with 8 waves (512 threads; the fp32 128x64 variant uses BK = 32)
-//     10 = 128x128 wave-specialised (split-bf16 forward/dgrad kernels only; fp32 kernels map it to 0)
-//     11 = 64x64 on v_mfma_f32_16x16x4_f32 (fp32 kernels)
+// ---- tile selection of the fp32-MFMA forward / input-gradient kernel (ctn_tune("pw_tile", id) / CTN_PW_TILE override it) ----
+// id: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64
 extern int g_ctn_tile_override;   // -2: not read yet, -1: heuristic (defined in ctn_gemm.hip)
 
 static void tile_dims(int id, int* tm, int* tn) {
-    static const int d[12][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 64}, {64, 64}, {128, 64}, {128, 128}, {128, 128}, {128, 64}, {128, 128}, {64, 64}};
+    static const int d[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     *tm = d[id][0];
     *tn = d[id][1];
 }
@@ -366,13 +274,12 @@ static int pick_tile(int M, int R, int Kp) {
     if (g_ctn_tile_override == -2) {
         const char* e = getenv("CTN_PW_TILE");
         g_ctn_tile_override = (e && *e) ? atoi(e) : -1;
-        if (g_ctn_tile_override < -1 || g_ctn_tile_override > 11) g_ctn_tile_override = -1;
+        if (g_ctn_tile_override < -1 || g_ctn_tile_override > 3) g_ctn_tile_override = -1;
     }
     if (g_ctn_tile_override >= 0) return g_ctn_tile_override;
     // Measured on MI355X (benchmarks/gemm_sweep.py, paper shapes): 64x64 tiles win every variant -- 3200 / 1600
     // workgroups balance over the 256 CUs far better than 800 / 400 tiles of 128x128, and one fp32 MFMA (64 cycles)
     // needs so little operand bandwidth that the smaller tile's lower reuse costs nothing.
     (void)M; (void)R; (void)Kp;
-    const int best_id = 3;
-    return best_id;
+    return 3;
 }

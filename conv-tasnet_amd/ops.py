@@ -25,30 +25,6 @@ F32 = torch.float32
 F64 = torch.float64
 BF16 = torch.bfloat16
 
-# _GEMM_MODE "x6" = the round-1 split-bf16 experiment (include/ctn_hip_experimental.h): only with a CTN_BUILD_X6=1 library
-# and CTN_EXPERIMENTAL=1.  The product arithmetics (b6 default / fp32 / b3) are selected by set_gemm_arith below.
-_GEMM_MODE = "fp32"
-
-
-def set_gemm_mode(mode):
-    global _GEMM_MODE
-    if mode not in ("fp32", "x6"):
-        raise ValueError("gemm mode must be 'fp32' or 'x6'")
-    if mode == "x6":
-        from ._lib import EXPERIMENTAL
-        if not EXPERIMENTAL:
-            raise CtnError("gemm mode 'x6' is an experiment: build with CTN_BUILD_X6=1 and run with CTN_EXPERIMENTAL=1")
-    _GEMM_MODE = mode
-
-
-if os.environ.get("CTN_GEMM_MODE", "fp32") != "fp32":
-    set_gemm_mode(os.environ["CTN_GEMM_MODE"])
-
-
-def gemm_mode():
-    return _GEMM_MODE
-
-
 _ARITH_NAMES = ("fp32", "b3", "b6")        # ids of ctn_gemm_arith / ctn_tune("arith", id)
 
 
@@ -81,14 +57,6 @@ class gemm_arithmetic:
     def __exit__(self, *exc):
         set_gemm_arith(self.prev)
         return False
-
-
-def _split_planes(W, rows, cols, transpose):
-    """[3][R][Cnp] bf16 planes of a weight matrix (W^T when transpose)."""
-    R, Cn = (cols, rows) if transpose else (rows, cols)
-    planes = torch.empty((3, R, lib.ctn_split_cols(Cn)), dtype=BF16, device=W.device)
-    lib.call("ctn_split_bf16", _p(W), _p(planes), rows, cols, int(transpose), _stream())
-    return planes
 
 
 def _p(t):
@@ -164,13 +132,6 @@ def pw_gemm(W, X, R, Cn, K, trans_w=False, pro=None, residual=None, epi_alpha=No
     pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
     _chk(W, X, pg, pb, pa, residual, epi_alpha, ms_out)
     _chk_aux(pp)
-    if _GEMM_MODE == "x6":
-        wr, wc = (Cn, R) if trans_w else (R, Cn)                 # W as stored
-        planes = _split_planes(W, wr, wc, trans_w)
-        lib.call("ctn_pw_gemm_x6", _p(planes), _p(X), _p(out), M, R, Cn, K, Kp,
-                 _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(residual), _p(epi_alpha), _p(epi_part),
-                 int(relu_out), _stream())
-        return out, epi_part
     tw = int(trans_w)
     if _b3_planes_ok(R) and not relu_out:
         W, tw = _b3_pieces(W, R, Cn, bool(trans_w)), 2           # the product kernel of the split-bf16 arithmetics (pre-split weights)
@@ -199,11 +160,7 @@ def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
     dn = torch.empty((M, R, Kp), dtype=F32, device=dOut.device)
     part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=dOut.device)
     _chk(W, dOut, y, gamma, alpha, ms)
-    if _GEMM_MODE == "x6":
-        planes = _split_planes(W, Cn, R, True)
-        lib.call("ctn_pw_dgrad_gln_x6", _p(planes), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha),
-                 _p(ms), _p(part), _stream())
-    elif _b3_planes_ok(R):
+    if _b3_planes_ok(R):
         lib.call("ctn_pw_dgrad_gln_planes", _p(_b3_pieces(W, R, Cn, True)), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma),
                  _p(alpha), _p(ms), _p(part), _stream())
     else:
@@ -279,24 +236,15 @@ def _workspace(nbytes, device, tag):
     return buf
 
 
-_wgrad_tuned = False
-
-
 def pw_wgrad(dOut, X, R, Cn, K, pro=None, out=None, ws_tag="wgrad"):
     """dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2]).  out: optional destination."""
-    global _wgrad_tuned
-    if not _wgrad_tuned:            # tuning knobs of the split-K plan: output tile (64 | 12864 | 128) and target workgroups per launch (512)
-        _wgrad_tuned = True
-        if os.environ.get("CTN_WGRAD_BLOCKS") or os.environ.get("CTN_WGRAD_TILE"):
-            lib.call("ctn_tune_wgrad", int(os.environ.get("CTN_WGRAD_TILE", "0")), int(os.environ.get("CTN_WGRAD_BLOCKS", "512")))
     M, _, Kp = X.shape
     dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
-    x6 = _GEMM_MODE == "x6"
-    nbytes = (lib.ctn_pw_wgrad_x6_workspace if x6 else lib.ctn_pw_wgrad_workspace)(M, R, Cn, Kp)
+    nbytes = lib.ctn_pw_wgrad_workspace(M, R, Cn, Kp)
     ws = _workspace(nbytes, X.device, ws_tag)
     pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
     _chk(dOut, X, pg, pb, pa, pms)
-    lib.call("ctn_pw_wgrad_x6" if x6 else "ctn_pw_wgrad", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb),
+    lib.call("ctn_pw_wgrad", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb),
              _p(pa), _p(pms), _p(ws), nbytes, _stream())
     return dW
 

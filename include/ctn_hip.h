@@ -39,15 +39,15 @@ int ctn_padded_frames(int K);               /* K rounded up to a multiple of 64 
  * torch.cuda.Stream.wait_stream for the weight-gradient stream of the backward pass. */
 int ctn_stream_order(void* from, void* to);
 
-/* ---- 1x1 convolutions = fp32-MFMA GEMMs ------------------------------------------------
+/* ---- 1x1 convolutions = GEMMs on the matrix cores, fp32-faithful ------------------------
  * replaces nn.Conv1d(*, *, 1, bias=False): src/conv_tasnet.py:174 (bottleneck), :191 (mask),
  * :223 and :262 (TemporalBlock), and the Linear of the decoder (:128,:143); autograd's
  * convolution_backward for the same layers. */
 
 /* Out[m] = op(W) . f(X[m])  (+ residual[m]),   X:[M,Cn,Kp]  Out:[M,R,Kp]
  *   trans_w = 0: W is [R,Cn] (forward);  trans_w = 1: W is [Cn,R] (input gradient, or forward on a transposed copy:
- *     the fast form of the fp32 arithmetic -- ctn_transpose_batch);  trans_w = 2: W is a block of pre-split bf16 pieces
- *     from ctn_split_b3_batch (b3 arithmetic, R >= 64: the fast form there).
+ *     the fast form of the fp32-MFMA arithmetic -- ctn_transpose_batch);  trans_w = 2: W is a block of pre-split bf16 pieces
+ *     from ctn_split_b3_batch (split-bf16 arithmetics b6 / b3, R >= 64: the fast form there).
  *   pro_part != NULL: f(x)[i,k] = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i]
  *     for k < K, 0 otherwise; (mean_m, rstd_m) are finalised from the [M, pro_nparts, 2] fp64
  *     (sum, sum of squares) partials of prelu(x) -- global LayerNorm, src/conv_tasnet.py:358-360 --
@@ -61,8 +61,6 @@ int ctn_pw_gemm(const float* W, const float* X, float* Out, int M, int R, int Cn
                 const float* pro_alpha, float* pro_ms_out,
                 const float* residual, const float* epi_alpha, double* epi_part, int relu_out, void* stream);
 int ctn_pw_stats_parts(int M, int R, int Kp);
-/* experiment / autotune hook: force GEMM tile id 0..4 (128x128, 128x64, 64x128, 64x64, 128x64 4x1 waves); -1 = heuristic */
-int ctn_tune_pw_tile(int id);
 
 /* dst[i] = src[i]^T for n equally shaped [rows, cols] fp32 matrices (HOST arrays of device pointers): the forward pass
  * keeps a [I, O] copy of every 1x1 weight [O, I] so that ctn_pw_gemm(trans_w = 1) -- 16-byte row writes into LDS, no
@@ -83,48 +81,33 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
                  const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
                  void* workspace, size_t workspace_bytes, void* stream);
 size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
-/* experiment / autotune hook: output tile (0 = heuristic, 64, 128 square, 12864 = 128 x 64) and target workgroups per launch (default 512);
- * call before sizing workspaces */
-int ctn_tune_wgrad(int tile, int blocks);
-/* experiment hook for in-process A/B measurements: key in {"pk", "pk_wgs", "wgrad_kernel", "wgrad_blocks"} (the switches the
- * CTN_PW_KERNEL / CTN_PK_WGS / CTN_WGRAD_KERNEL / CTN_WGRAD_BLOCKS environment variables set at first use).  Change them
- * only between steps (workspace sizes and statistics layouts depend on them). */
+/* Library switches (process-global; the library is driven by ONE host thread at a time: set them from that thread, between
+ * steps -- workspace sizes and statistics layouts depend on them).  Keys: "arith" (below); "b3_tile" / "b3_tile_k3" 0|1|2 =
+ * 128x128 / 128x64 / 256x64 tile of the split-bf16 forward / input-gradient kernels (the prologue + residual form has its
+ * own); "b3_wgrad_blocks", "wgrad_blocks": target workgroups per weight-gradient launch (split-bf16 / fp32 MFMA);
+ * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE).  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
- *   1 = "b3": every fp32 operand is split into two bf16 pieces (round-to-nearest-even) and a.b is formed from the three
- *       piece-products of weight >= 2^-9 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- products carry >= 16
- *       significand bits; whole-model SI-SNR within ~1e-4 dB of the fp32 path (budget 1e-3 dB);
- *   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains.
- * Selected by CTN_GEMM_ARITH=b3|fp32 at first use or ctn_tune("arith", 0|1) between steps; layers with fewer than 64
- * output rows always use the fp32 kernels. */
+ *   2 = "b6" (default): every fp32 operand is split EXACTLY into three bf16 pieces (a = a0 + a1 + a2, round-to-nearest-even)
+ *       and a.b is formed from the six piece-products of weight >= 2^-17 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
+ *       the dropped terms are <= 2^-23 |a.b| -- one fp32 rounding of the product.  Measured against fp64 the error of every
+ *       GEMM form is that of the fp32 MFMA (3.4e-7 vs 4.0e-7 of sum |a||b|, profiles/r03_a_b6_check.txt);
+ *   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains;
+ *   1 = "b3" (opt-in, NOT reference precision): two pieces per operand, three products, ~16 significant bits per product.
+ * Selected by CTN_GEMM_ARITH=b6|fp32|b3 at first use or ctn_tune("arith", 2|0|1) between steps; layers with fewer than 64
+ * output rows (and weight gradients with a side below 32) always use the fp32-MFMA kernels. */
 int ctn_gemm_arith(void);
-/* b3 arithmetic only: the weight operand pre-split once per step.  dst[i] receives the two bf16 pieces of the GEMM operand
+/* Split-bf16 arithmetics only: the weight operand pre-split once per step.  dst[i] receives the bf16 pieces of the GEMM operand
  * A [R, Cn] (rows = output channels of THAT GEMM, Cn = its contraction) in MFMA fragment order, zero-filled to multiples
- * of 32: ctn_split_b3_bytes(R, Cn) bytes each, 16-byte aligned.  k_major = 0: src[i] is stored [R, Cn] (forward layers);
- * k_major = 1: src[i] is stored [Cn, R] and used transposed (input gradients of the same layers).  HOST arrays of device
- * pointers, any n.  ctn_pw_gemm(trans_w = 2) and ctn_pw_dgrad_gln_planes take such a block as W: no conversion work and
- * no LDS traffic for the weights inside the GEMM; results are bitwise those of the fp32-weight forms under b3. */
+ * of 32: ctn_split_b3_bytes(R, Cn) bytes each (three pieces under b6, two under b3), 16-byte aligned.  k_major = 0: src[i] is
+ * stored [R, Cn] (forward layers); k_major = 1: src[i] is stored [Cn, R] and used transposed (input gradients of the same
+ * layers).  HOST arrays of device pointers, any n.  ctn_pw_gemm(trans_w = 2) and ctn_pw_dgrad_gln_planes take such a block as
+ * W: no conversion work and no LDS traffic for the weights inside the GEMM; results are bitwise those of the fp32-weight forms. */
 size_t ctn_split_b3_bytes(int R, int Cn);
 int ctn_split_b3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream);
 int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
                             const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
                             void* stream);
-
-/* b3 arithmetic: the backward pass of "gLN(PReLU(y))" (ctn_gln_prelu_bwd below) folded into its two consumers, so that the
- * gradient with respect to the norm's OUTPUT (dN) is their operand and the input gradient dY is never written:
- *   dY = rstd*(gamma*dN - S1/n - xh*S2/n) * prelu'(y),  xh = (prelu(y,alpha) - mean)*rstd,  (mean, rstd) = ms [M,2],
- *   (S1, S2) = sums of the [M, nparts, 2] fp64 partials sums_part, n = channels*K  (src/conv_tasnet.py:224-225,338-361 backward).
- * ctn_pw_gemm_glnbwd:  Out[m] = Wp . dY[m] + residual[m]   (Wp: pieces of the [R, Cn] operand from ctn_split_b3_batch; dN, y: [M,Cn,Kp]).
- * ctn_pw_wgrad_glnbwd: dW[R,Cn] = sum_{m,k} dY[m,r,k] * X[m,c,k]  (dN, y: [M,R,Kp]) and the PReLU-slope gradient as
- *   ctn_pw_wgrad_glnbwd_parts(M,R,Cn,Kp) partial sums dalpha_part (add them in order; ctn_dw_bwd_finalize does).
- * dY is bit for bit what ctn_gln_prelu_bwd writes, so Out and dW equal the unfused sequence bitwise. */
-int ctn_pw_gemm_glnbwd(const void* Wp, const float* dN, const float* y, float* Out, int M, int R, int Cn, int K, int Kp,
-                       const double* sums_part, int nparts, const float* gamma, const float* alpha, const float* ms,
-                       const float* residual, void* stream);
-int ctn_pw_wgrad_glnbwd(const float* dN, const float* y, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
-                        const double* sums_part, int nparts, const float* gamma, const float* alpha, const float* ms,
-                        float* dalpha_part, void* workspace, size_t workspace_bytes, void* stream);
-int ctn_pw_wgrad_glnbwd_parts(int M, int R, int Cn, int Kp);
 
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the

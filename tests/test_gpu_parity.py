@@ -679,9 +679,9 @@ def test_bn_trains_with_flat_adam_and_standalone_module():
 
 
 # ----------------------------------------------------------------------------- plan / width variants of the kernels
-@pytest.mark.parametrize("tile,blocks", [(64, 256), (12864, 512), (128, 512), (64, 1024)])
-def test_pw_wgrad_every_plan(fp32_only, tile, blocks):
-    """The split-K weight gradient under every tile / workgroup plan ctn_tune_wgrad offers (ragged R, Cn, K)."""
+@pytest.mark.parametrize("blocks", [64, 256, 1024])
+def test_pw_wgrad_every_plan(fp32_only, blocks):
+    """The fp32-MFMA split-K weight gradient under several workgroup plans (ragged R, Cn, K)."""
     M, R, Cn, K = 3, 200, 132, 1301
     Kp = ops.padded_frames(K)
     dO = pad(torch.randn(M, R, K, generator=g(11)), Kp)
@@ -694,11 +694,13 @@ def test_pw_wgrad_every_plan(fp32_only, tile, blocks):
     xn[..., K:] = 0
     ref_pro = torch.einsum("mrk,mck->rc", dO.double(), xn.double())
     try:
-        ctn.lib.call("ctn_tune_wgrad", tile, blocks)
+        ctn.lib.call("ctn_tune", b"wgrad_blocks", blocks)
+        ops._ws_cache.clear()
         out = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K)
         out_pro = ops.pw_wgrad(dO.to(DEV), X.to(DEV), R, Cn, K, pro=(gam.to(DEV), bet.to(DEV), al.to(DEV), ms.to(DEV)))
     finally:
-        ctn.lib.call("ctn_tune_wgrad", 0, 512)
+        ctn.lib.call("ctn_tune", b"wgrad_blocks", 512)
+        ops._ws_cache.clear()
     assert rel_err(out, ref) < 5e-6
     assert rel_err(out_pro, ref_pro) < 5e-6
 
@@ -750,27 +752,6 @@ def test_stream_order_entry_point():
         ctn.lib.call("ctn_stream_order", s2.cuda_stream, s1.cuda_stream)
 
 
-# ----------------------------------------------------------------------------- persistent GEMM family (CTN_PW_KERNEL=2)
-@pytest.fixture
-def persistent_gemms(fp32_only):
-    """Select the persistent fp32-MFMA kernels (pw_gemm_pk_kernel) for one test, the default family afterwards."""
-    ctn.lib.call("ctn_tune", b"pk", 1)
-    yield
-    ctn.lib.call("ctn_tune", b"pk", 0)
-    ops._ws_cache.clear()
-
-
-def test_persistent_gemm_family_matches_fp64(persistent_gemms):
-    """Every form of the persistent kernel -- stored and transposed weights, odd k-tile counts, row-overhanging tiles,
-    ReLU / residual / statistics epilogues, gLN prologue, gLN-backward sums -- against fp64 torch."""
-    for (M, R, Cn, K) in [(1, 128, 16, 64), (2, 32, 64, 799), (3, 132, 20, 130), (2, 256, 512, 515), (2, 512, 256, 1000)]:
-        for trans in (False, True):
-            test_pw_gemm_plain(M, R, Cn, K, trans)
-    test_pw_gemm_asymmetric_identity()
-    test_pw_gemm_relu_and_stats_and_prologue()
-    _forward_forms_on_transposed_weights()
-
-
 def _forward_forms_on_transposed_weights():
     """K1 / K3 forms of ctn_pw_gemm on a transposed weight copy (trans_w = 1 + statistics epilogue / gLN prologue + residual):
     what the composite stack launches.  R = 40 overhangs the 64-row tile: with trans_w = 1 the overhanging accumulator rows
@@ -804,49 +785,7 @@ def test_forward_forms_on_transposed_weights_default_family():
     _forward_forms_on_transposed_weights()
 
 
-@pytest.mark.parametrize("norm_type,causal,dil_x,K", [("gLN", False, 3, 799), ("gLN", True, 7, 1203), ("cLN", True, 2, 3700)])
-def test_temporal_block_on_persistent_gemms(persistent_gemms, norm_type, causal, dil_x, K):
-    test_temporal_block_fwd_bwd(norm_type, causal, dil_x, K)
-
-
-def test_tiny_model_on_persistent_gemms(persistent_gemms):
-    """Whole model (composite stack: transposed weight copies + persistent kernels) against the reference fixture."""
-    test_model_matches_reference_golden("model_tiny_gln")
-
-
-# ----------------------------------------------------------------------------- v_mfma_f32_16x16x4_f32 forms
-@pytest.fixture
-def mfma16_kernels(fp32_only):
-    """GEMM tile 11 (64x64 on v_mfma_f32_16x16x4_f32) and the 16x16x4 weight-gradient kernel for one test."""
-    ctn.lib.call("ctn_tune", b"pw_tile", 11)
-    ctn.lib.call("ctn_tune", b"wgrad_mf", 16)
-    yield
-    ctn.lib.call("ctn_tune", b"pw_tile", -1)
-    ctn.lib.call("ctn_tune", b"wgrad_mf", 32)
-    ops._ws_cache.clear()
-
-
-def test_mfma16_gemm_family_matches_fp64(mfma16_kernels):
-    for (M, R, Cn, K) in [(1, 128, 16, 64), (2, 32, 64, 799), (3, 132, 20, 130), (2, 256, 512, 515), (2, 512, 256, 1000)]:
-        for trans in (False, True):
-            test_pw_gemm_plain(M, R, Cn, K, trans)
-    test_pw_gemm_asymmetric_identity()
-    test_pw_gemm_relu_and_stats_and_prologue()
-    for case in [(2, 64, 64, 799), (3, 512, 256, 1300), (1, 132, 72, 300)]:
-        test_pw_wgrad(*case)
-    _forward_forms_on_transposed_weights()
-
-
-@pytest.mark.parametrize("norm_type,causal,dil_x,K", [("gLN", False, 3, 799), ("gLN", True, 7, 1203)])
-def test_temporal_block_on_mfma16(mfma16_kernels, norm_type, causal, dil_x, K):
-    test_temporal_block_fwd_bwd(norm_type, causal, dil_x, K)
-
-
-def test_tiny_model_on_mfma16(mfma16_kernels):
-    test_model_matches_reference_golden("model_tiny_gln")
-
-
-# ----------------------------------------------------------------------------- b3 arithmetic: kernel forms of its own
+# ----------------------------------------------------------------------------- split-bf16 arithmetics: kernel forms of its own
 def _raw_pw_gemm(W, X, R, Cn, K, tw, residual=None):
     """ctn_pw_gemm through the raw C ABI (ops.pw_gemm routes b3 calls to the pre-split weight pieces)."""
     M, _, Kp = X.shape
@@ -966,55 +905,3 @@ def test_encoder_kernel_matches_conv1d(L, N, T, M):
     assert float(w[..., K:].abs().max()) == 0.0
     with pytest.raises(ctn.CtnError):
         ctn.lib.call("ctn_encoder_fwd", ops._p(mix_d), ops._p(U_d), ops._p(w), M, T, N, 24, K, Kp, ops._stream())
-
-
-def test_gln_backward_folded_into_its_consumers():
-    """ctn_pw_gemm_glnbwd / ctn_pw_wgrad_glnbwd (b3): the gLN'/PReLU' backward pass applied in the operand prologues of the
-    input-gradient GEMM and of the weight gradient, against ctn_gln_prelu_bwd followed by the plain forms -- bitwise for the
-    tensors, fp32 round-off for the PReLU-slope gradient (another fixed summation order) -- and against fp64 torch."""
-    if ARITH["name"] == "fp32":
-        pytest.skip("split-bf16 kernels")
-    M, B, H, K = 3, 72, 136, 1203
-    Kp = ops.padded_frames(K)
-    dn = pad(torch.randn(M, H, K, generator=g(51)), Kp).to(DEV)
-    y = pad(torch.randn(M, H, K, generator=g(52)), Kp).to(DEV)
-    x = pad(torch.randn(M, B, K, generator=g(53)), Kp).to(DEV)
-    res = pad(torch.randn(M, B, K, generator=g(54)), Kp).to(DEV)
-    w1 = (torch.randn(H, B, generator=g(55)) * 0.2).to(DEV)
-    gam = torch.randn(1, H, 1, generator=g(56)).to(DEV)
-    al = torch.tensor([0.3], device=DEV)
-    ms = torch.tensor([[0.1, 1.3], [-0.2, 0.7], [0.05, 1.1]], device=DEV)
-    # sums partials [M, H, 2] as dw_bwd emits them: S1 = sum gamma*dn, S2 = sum gamma*dn*xh per (utterance, channel)
-    pre = torch.where(y >= 0, y, al * y)
-    xh = (pre - ms[:, 0].view(-1, 1, 1)) * ms[:, 1].view(-1, 1, 1)
-    t = gam * dn
-    part = torch.stack([t[..., :K].double().sum(-1), (t * xh)[..., :K].double().sum(-1)], -1).contiguous()
-    # unfused: B4 in place, then the plain GEMMs
-    dh1 = torch.empty_like(dn)
-    dap = torch.empty(M * H, device=DEV)
-    ctn.lib.call("ctn_gln_prelu_bwd", ops._p(dn), ops._p(y), ops._p(dh1), M, H, K, Kp, ops._p(gam), ops._p(al), ops._p(ms),
-                 ops._p(part), H, ops._p(dap), ops._stream())
-    pieces = ops._b3_pieces(w1, B, H, True)                   # operand [R = B, Cn = H] of dx = W1^T . dh1
-    dx_ref = _raw_pw_gemm(pieces, dh1, B, H, K, 2, res)
-    dW_ref = ops.pw_wgrad(dh1, x, H, B, K)
-    # fused
-    dx = torch.empty((M, B, Kp), device=DEV)
-    ctn.lib.call("ctn_pw_gemm_glnbwd", ops._p(pieces), ops._p(dn), ops._p(y), ops._p(dx), M, B, H, K, Kp, ops._p(part), H, ops._p(gam),
-                 ops._p(al), ops._p(ms), ops._p(res), ops._stream())
-    nparts = ctn.lib.ctn_pw_wgrad_glnbwd_parts(M, H, B, Kp)
-    dap2 = torch.empty(nparts, device=DEV)
-    dW = torch.empty((H, B), device=DEV)
-    nbytes = ctn.lib.ctn_pw_wgrad_workspace(M, H, B, Kp)
-    wsb = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    ctn.lib.call("ctn_pw_wgrad_glnbwd", ops._p(dn), ops._p(y), ops._p(x), ops._p(dW), M, H, B, K, Kp, ops._p(part), H, ops._p(gam), ops._p(al),
-                 ops._p(ms), ops._p(dap2), ops._p(wsb), nbytes, ops._stream())
-    assert torch.equal(dx, dx_ref) and torch.equal(dW, dW_ref)
-    assert abs(float(dap2.sum()) - float(dap.sum())) <= 2e-5 * float(dap.abs().sum())
-    # and fp64: dY = rstd*(gamma*dn - S1/n - xh*S2/n) * prelu'(y) over frames < K
-    n = H * K
-    S1, S2 = part[..., 0].sum(1).view(-1, 1, 1), part[..., 1].sum(1).view(-1, 1, 1)
-    dy = ms[:, 1].view(-1, 1, 1).double() * (t.double() - S1 / n - xh.double() * S2 / n) * torch.where(y >= 0, 1.0, 0.3).double()
-    dy[..., K:] = 0
-    ref = torch.einsum("cr,mck->mrk", w1.double(), dy) + res.double()
-    assert rel_err(dx[..., :K], ref[..., :K]) < 5e-6
-    assert rel_err(dW, torch.einsum("mrk,mck->rc", dy, x.double())) < 5e-6
