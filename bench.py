@@ -46,6 +46,9 @@ CONFIGS = {
                    name="BASELINE configs[3]: causal cLN variant N256 L20 B256 H512 P3 X8 R4 C2, %d x 4s@8kHz"),
     "c3": dict(model=dict(N=256, L=16, B=256, H=512, P=3, X=8, R=4, C=3), norm_type="gLN", causal=False, T=64000, sr=16000,
                name="BASELINE configs[4]: 3-speaker C3 L16 N256 B256 H512 P3 X8 R4 gLN, %d x 4s@16kHz"),
+    # the reference's own CPU-runnable case (a parity-test config, and the N > 1 rehearsal of tests/test_bench_dp_gpu.py): not a bench line
+    "tiny": dict(model=dict(N=64, L=20, B=32, H=64, P=3, X=2, R=2, C=2), norm_type="gLN", causal=False, T=8000, sr=8000, batch=2,
+                 name="BASELINE configs[0]: tiny N64 L20 B32 H64 P3 X2 R2 gLN C2, %d x 1s@8kHz"),
 }
 
 
@@ -336,6 +339,8 @@ def main():
                     help="1: replay zero_grad+fwd+loss+bwd from one captured HIP graph (conv_tasnet_amd.graphed)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    global PER_GPU_BATCH
+    PER_GPU_BATCH = cfg.get("batch", PER_GPU_BATCH)
 
     import torch.distributed as dist
     import conv_tasnet_amd as ctn
@@ -355,6 +360,7 @@ def main():
     model = ctn.ConvTasNet(**cfg["model"], norm_type=cfg["norm_type"], causal=cfg["causal"], mask_nonlinear="relu").to(device)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     parallel.broadcast_parameters(opt.flat_params)
+    parallel.enable_overlap(opt, cfg["model"]["X"])      # N > 1: one all-reduce bucket per repeat, issued during the backward pass
     # this rank's shard: utterances [rank*8, rank*8+8) of the deterministic harmonic-mixture workload
     mix, lens, src = next(iter(SyntheticLoader(1, PER_GPU_BATCH, samples=cfg["T"], C=cfg["model"]["C"], sample_rate=cfg["sr"],
                                                rank=rank, world=world)))

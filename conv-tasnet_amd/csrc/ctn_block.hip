@@ -213,7 +213,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
                     const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
                     const float* dout, float* dxs, float* dn1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags) {
     CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && dout && dxs && dn1s && workspace,
                 "ctn_tcn_gln_bwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_bwd: bad sizes");
@@ -288,7 +288,9 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = finalize(stream))) return rc;
         }
     }
-    if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;
+    // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
+    // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)
+    if (side_stream && !(flags & 1) && (rc = ctn_stream_order(side_stream, stream))) return rc;
     return CTN_OK;
 }
 
@@ -372,7 +374,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
                     const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
                     const float* st, const float* dout, float* dxs, float* dh1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags) {
     CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && dout && dxs && dh1s && workspace,
                 "ctn_tcn_cln_bwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_bwd: bad sizes");
@@ -428,7 +430,9 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream)))) return rc;
         if (!side_stream && (rc = PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
     }
-    if (side_stream && (rc = ctn_stream_order(side_stream, stream))) return rc;
+    // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
+    // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)
+    if (side_stream && !(flags & 1) && (rc = ctn_stream_order(side_stream, stream))) return rc;
     return CTN_OK;
 }
 

@@ -464,6 +464,23 @@ class GlnBlock(torch.autograd.Function):
 import ctypes  # noqa: E402
 
 _COMPOSITE = os.environ.get("CTN_COMPOSITE", "1") != "0"
+_GRAD_BUCKETS = None     # parallel.GradientBuckets: the stack's backward is then issued bucket by bucket (enable_overlap)
+
+
+def set_grad_buckets(gb):
+    global _GRAD_BUCKETS
+    _GRAD_BUCKETS = gb
+
+
+def _bucket_ranges(nb, direct):
+    """Block ranges [lo, hi) of the stack's backward calls, last blocks first: one call for the whole stack, or one per
+    gradient bucket when an overlapped all-reduce is installed and the gradients go straight into the flat buffer."""
+    gb = _GRAD_BUCKETS
+    if gb is None or not direct or gb.blocks_per_bucket <= 0 or gb.blocks_per_bucket >= nb:
+        return [(0, nb)], None
+    per = gb.blocks_per_bucket
+    return [(max(hi - per, 0), hi) for hi in range(nb, 0, -per)], gb
+
 NPARAM = 9       # per block: w1, a1, g1, b1, D, a2, g2, b2, w2  (order of include/ctn_hip.h)
 
 
@@ -554,9 +571,21 @@ class TcnGln(torch.autograd.Function):
         nbytes = lib.ctn_tcn_gln_bwd_workspace(M, B, H, Kp, P, nb)
         ws = _workspace(nbytes, dev, "tcn_bwd")
         side = _side_stream(dev) if (direct and _SIDE_ENABLED) else None
-        lib.call("ctn_tcn_gln_bwd", _ptr_table(params), _ptr_table(gdst), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms),
-                 _p(dout), _p(dxs), _p(dn1s), M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(),
-                 0 if side is None else side.cuda_stream)
+        ranges, gb = _bucket_ranges(nb, direct)
+        for i, (lo, hi) in enumerate(ranges):
+            # gradient buckets: every call but the last leaves the weight-gradient stream un-joined (its own workspace), and the
+            # bucket's all-reduce is issued BEHIND that stream -- all parameter gradients of the stack are produced there --
+            # while the main stream already runs the next bucket's chain
+            unjoined = gb is not None and side is not None and i + 1 < len(ranges)
+            nbi = lib.ctn_tcn_gln_bwd_workspace(M, B, H, Kp, P, hi - lo) if gb is not None else nbytes
+            wsi = _workspace(nbi, dev, "tcn_bwd_bucket%d" % i) if unjoined else ws
+            lib.call("ctn_tcn_gln_bwd", _ptr_table(params[lo * NPARAM:hi * NPARAM]), _ptr_table(gdst[lo * NPARAM:hi * NPARAM]),
+                     (ctypes.c_int * (hi - lo))(*dil[lo:hi]), hi - lo, _p(x0 if lo == 0 else xs[lo - 1]), _p(xs[lo]), _p(h1s[lo]),
+                     _p(ds[lo]), _p(ms[lo]), _p(dout if hi == nb else dxs[hi]), _p(dxs[lo]), _p(dn1s[lo]), M, B, H, K, Kp, P,
+                     int(causal), _p(wsi), nbi, _stream(), 0 if side is None else side.cuda_stream, int(unjoined))
+            if gb is not None:
+                with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):
+                    gb.bucket_ready(gdst[lo * NPARAM:hi * NPARAM])
         ctx.acts = None             # release 4 GB of saved activations as soon as they are consumed
         # the call joined the side stream into the current one, so stream-ordered reuse of these buffers is safe
         if direct:
@@ -641,9 +670,18 @@ class TcnCln(torch.autograd.Function):
         nbytes = lib.ctn_tcn_cln_bwd_workspace(M, B, H, Kp, P, nb)
         ws = _workspace(nbytes, dev, "tcn_cln_bwd")
         side = _side_stream(dev) if (direct and _SIDE_ENABLED and _CLN_SIDE) else None
-        lib.call("ctn_tcn_cln_bwd", _ptr_table(params), _ptr_table(gdst), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]),
-                 _p(hs[3]), _p(st), _p(dout), _p(dxs), _p(dh1s), M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(),
-                 0 if side is None else side.cuda_stream)
+        ranges, gb = _bucket_ranges(nb, direct)
+        for i, (lo, hi) in enumerate(ranges):            # (gradient buckets: as in TcnGln.backward)
+            unjoined = gb is not None and side is not None and i + 1 < len(ranges)
+            nbi = lib.ctn_tcn_cln_bwd_workspace(M, B, H, Kp, P, hi - lo) if gb is not None else nbytes
+            wsi = _workspace(nbi, dev, "tcn_cln_bwd_bucket%d" % i) if unjoined else ws
+            lib.call("ctn_tcn_cln_bwd", _ptr_table(params[lo * NPARAM:hi * NPARAM]), _ptr_table(gdst[lo * NPARAM:hi * NPARAM]),
+                     (ctypes.c_int * (hi - lo))(*dil[lo:hi]), hi - lo, _p(x0 if lo == 0 else xs[lo - 1]), _p(xs[lo]), _p(hs[0][lo]),
+                     _p(hs[1][lo]), _p(hs[2][lo]), _p(hs[3][lo]), _p(st[lo]), _p(dout if hi == nb else dxs[hi]), _p(dxs[lo]), _p(dh1s[lo]),
+                     M, B, H, K, Kp, P, int(causal), _p(wsi), nbi, _stream(), 0 if side is None else side.cuda_stream, int(unjoined))
+            if gb is not None:
+                with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):
+                    gb.bucket_ready(gdst[lo * NPARAM:hi * NPARAM])
         ctx.acts = None
         if direct:
             return (dxs[0], None, None, None) + (None,) * len(params)

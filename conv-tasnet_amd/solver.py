@@ -72,6 +72,9 @@ class Solver(object):
         self.iter_losses = []                         # every batch loss seen, python floats
         self._plot = self._make_plotter() if (a.visdom_enabled or a.visdom_epoch) else None
         self._rank0 = (not torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+        if isinstance(optimizer, FlatAdam):
+            # N > 1: the gradient all-reduce goes out in one bucket per repeat while the backward pass is still running
+            parallel.enable_overlap(optimizer, int(getattr(self.net, "X", 0) or 0))
         self._reset()
 
     # -- plumbing -----------------------------------------------------------------------------------

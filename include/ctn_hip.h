@@ -174,8 +174,12 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
  *     save = 0 (inference): xs needs 2 slots, h1s / ds / ms one slot each; the output is xs[(nblocks-1) & 1].
  *   backward: dout [M,B,Kp] gradient of the stack's output; dxs [nblocks][M,B,Kp] receives the gradient of every
  *     block's input (dxs[0] = gradient w.r.t. x0); dn1s [nblocks][M,H,Kp] scratch (one slot per block, read by the
- *     weight-gradient stream).  side_stream != NULL: weight-gradient GEMMs go there (forked / joined with
- *     ctn_stream_order); on return `stream` is ordered after all of them.
+ *     weight-gradient stream).  side_stream != NULL: weight-gradient GEMMs and the fixed-order parameter-gradient sums go
+ *     there (forked / joined with ctn_stream_order); on return `stream` is ordered after all of them -- unless flags bit 0
+ *     is set: then the second stream is left un-joined, so that the caller can put more work behind this call's gradients
+ *     (a data-parallel trainer: the all-reduce of this bucket of blocks) while `stream` already runs the next call; such a
+ *     call needs a workspace of its own, and the caller joins the streams itself (ctn_stream_order) before the gradients
+ *     are read on `stream`.  A stack may be run as several calls over consecutive block ranges (last blocks first).
  *   workspace: ctn_tcn_gln_{fwd,bwd}_workspace() bytes, 256-byte aligned. */
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* ds, float* ms, int save,
@@ -186,7 +190,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
                     const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
                     const float* dout, float* dxs, float* dn1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags);
 size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks);
 
 /* Measurement hook for the composite stacks (bench.py's roofline leg): ctn_probe_enable(1) makes every launch group issued
@@ -211,7 +215,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
                     const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
                     const float* st, const float* dout, float* dxs, float* dh1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags);
 size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks);
 
 /* ---- channel-wise LayerNorm, src/conv_tasnet.py:313-335 (per frame, biased variance) -----

@@ -75,6 +75,7 @@ def pytest_collection_finish(session):
     """Spawn tests/dp_worker.py (2 ranks + the single-process reference) if the DP GPU test was selected and a GPU exists.
     torch.cuda.device_count() does not initialise the GPU; the children run beside the other tests and are collected by
     tests/test_dp_gpu.py."""
+    _spawn_bench_children(session)
     if not any(it.nodeid.endswith("test_two_rank_product_training_matches_single_process") for it in session.items):
         return
     import subprocess
@@ -92,6 +93,41 @@ def pytest_collection_finish(session):
         procs[name] = subprocess.Popen([sys.executable, worker, str(rank), str(world), port, outs[name]],
                                        stdout=open(logs[name], "w"), stderr=subprocess.STDOUT, cwd=ROOT)
     _DP["children"] = (procs, outs, logs)
+
+
+def _spawn_bench_children(session):
+    """`bench.py --gpus 2 --steps 3 --warmup 1 --config tiny` as two env-rendezvous ranks on cuda:0 over gloo."""
+    if not any(it.nodeid.endswith("test_bench_two_ranks_prints_one_complete_line") for it in session.items):
+        return
+    import subprocess
+    import tempfile
+    import torch
+    if torch.cuda.device_count() < 1:
+        return
+    tmp = tempfile.mkdtemp(prefix="ctn_bench_dp_")
+    port = _free_port()
+    procs, outs, logs = {}, {}, {}
+    for rank in (0, 1):
+        name = "rank%d" % rank
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   CTN_DIST_BACKEND="gloo")
+        outs[name], logs[name] = os.path.join(tmp, name + ".out"), os.path.join(tmp, name + ".log")
+        procs[name] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_worker.py"), os.path.join(tmp, "go"), "--gpus", "2",
+                                        "--steps", "3", "--warmup", "1", "--config", "tiny"],
+                                       stdout=open(outs[name], "w"), stderr=open(logs[name], "w"), cwd=ROOT, env=env)
+    _DP["bench"] = (procs, outs, logs)
+    _DP["bench_go"] = os.path.join(tmp, "go")
+
+
+@pytest.fixture
+def bench_children():
+    if "bench" not in _DP:
+        pytest.skip("no GPU visible at collection time: the bench ranks were not started")
+    if "children" in _DP:                       # at most 6 processes may use the card: let the data-parallel children finish first
+        for p in _DP["children"][0].values():
+            p.wait(timeout=800)
+    open(_DP["bench_go"], "w").close()          # the two ranks wait for this file before they import torch
+    return _DP["bench"]
 
 
 @pytest.fixture

@@ -38,15 +38,29 @@ train = [batch(list(range(8 * b, 8 * b + 8))[split]) for b in range(3)]
 cv_all = [batch([500 + 2 * i, 501 + 2 * i]) for i in range(3)]
 cv = cv_all[rank::world]
 
-torch.manual_seed(100 + rank)                      # different initial weights per rank, until the broadcast
-model = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 2, 2).to(dev)
-opt = FlatAdam(model.parameters(), lr=1e-3)
-parallel.broadcast_parameters(opt.flat_params)
 save = out + ".dir"
-arg = (1, 1, 1, 1, 5, save, 0, "", "a.pth.tar", 1000, 0, 0, "x")
-sa = Solver({"tr_loader": train, "cv_loader": cv}, model, opt, arg)
-sa.train()
-res = {"losses": list(sa.iter_losses[:3]), "cv_a": float(sa.cv_loss[0]), "params": opt.flat_params.detach().cpu().clone()}
+
+
+def phase_a(overlap):
+    """3 training steps from the broadcast weights; overlap: the gradient all-reduce in per-repeat buckets issued behind the
+    weight-gradient stream during the backward pass (parallel.GradientBuckets) or as one collective after it."""
+    os.environ["CTN_DP_OVERLAP"] = "1" if overlap else "0"
+    torch.manual_seed(100 + rank)                  # different initial weights per rank, until the broadcast
+    model = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 2, 2).to(dev)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    parallel.broadcast_parameters(opt.flat_params)
+    arg = (1, 1, 1, 1, 5, save, 0, "", "a.pth.tar", 1000, 0, 0, "x")
+    sa = Solver({"tr_loader": train, "cv_loader": cv}, model, opt, arg)
+    assert (opt._ctn_buckets is not None) == (overlap and world > 1)
+    sa.train()
+    return model, opt, sa
+
+
+_, opt_plain, _ = phase_a(False)
+plain = opt_plain.flat_params.detach().clone()
+model, opt, sa = phase_a(True)
+res = {"losses": list(sa.iter_losses[:3]), "cv_a": float(sa.cv_loss[0]), "params": opt.flat_params.detach().cpu().clone(),
+       "buckets_equal_single_collective": bool(torch.equal(opt.flat_params, plain))}
 
 opt.param_groups[0]["lr"] = 1e-12
 arg = (1, 12, 1, 1, 5, save, 0, "", "b.pth.tar", 1000, 0, 0, "x")

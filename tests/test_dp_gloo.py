@@ -101,3 +101,53 @@ def test_global_minibatch_loss_weights_ragged_shards(tmp_path):
     # (1/world) * sum_r scale_r dloss_r/dx_r  ==  d/dx of the weighted mean:  scale_r = n_r * world / n
     for k, n in enumerate((5, 3)):
         assert abs(r[k]["grad"] - r[k]["dloss"] * n * 2 / 8) < 1e-6
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from conv_tasnet_amd import parallel
+    parallel.init_distributed(backend="gloo")
+
+    class Opt:                                   # what GradientBuckets needs of FlatAdam: the flat gradient buffer
+        pass
+    sizes = [30, 1, 8, 8, 24, 1, 8, 8, 30]       # one "block": 9 tensors, each padded to a multiple of 4 in the flat buffer
+    pad4 = lambda n: (n + 3) // 4 * 4            # noqa: E731
+    per_block = sum(pad4(n) for n in sizes)
+    front, nblocks, back = 52, 4, 20
+    total = front + nblocks * per_block + back
+    g = torch.Generator().manual_seed(7 + rank)
+    init = torch.randn(total, generator=g)
+    res = {}
+    for mode in ("single", "buckets"):
+        opt = Opt()
+        opt.flat_grads = init.clone()
+        if mode == "single":
+            opt._ctn_buckets = None
+        else:
+            gb = parallel.GradientBuckets(opt, blocks_per_bucket=2)
+            opt._ctn_buckets = gb
+            for lo in (2, 0):                    # backward order: last blocks first
+                sinks, o = [], front + lo * per_block
+                for _ in range(2):
+                    for n in sizes:
+                        sinks.append(opt.flat_grads[o:o + n])
+                        o += pad4(n)
+                gb.bucket_ready(sinks)
+            assert len(gb.covered) == 2
+        scale = parallel.allreduce_gradients(opt)
+        assert scale == 0.5
+        res[mode] = opt.flat_grads.clone()
+    torch.save(res, os.path.join(out_dir, "b%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_allreduce_equals_the_single_collective(tmp_path):
+    """parallel.GradientBuckets (the overlapped, per-repeat all-reduce of the flat gradient): buckets started out of order plus
+    the remainder reduce every element exactly once -- bitwise the result of one all-reduce of the whole buffer, on both ranks."""
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt")
+    assert torch.equal(r0["single"], r1["single"]) and torch.equal(r0["buckets"], r1["buckets"])
+    assert torch.equal(r0["single"], r0["buckets"])

@@ -18,6 +18,9 @@ def test_two_rank_product_training_matches_single_process(dp_children):
     r0, r1, one = (torch.load(outs[k], weights_only=True) for k in ("rank0", "rank1", "single"))
     # replicas stay bitwise identical: same reduced gradient, same optimiser kernel, same LR on both ranks
     assert torch.equal(r0["params"], r1["params"])
+    # the bucketed all-reduce issued during the backward pass (one bucket per repeat behind the weight-gradient stream + the
+    # remainder) gives bitwise the parameters of the single collective after it (two ranks: a + b == b + a)
+    assert r0["buckets_equal_single_collective"] and r1["buckets_equal_single_collective"] and one["buckets_equal_single_collective"]
     # ragged shards (5 + 3 utterances): the weighted global-minibatch loss equals the single-process loss on all 8
     for a, b, c in zip(r0["losses"], r1["losses"], one["losses"]):
         assert a == b, "ranks report different global losses"
