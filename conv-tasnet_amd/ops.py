@@ -535,9 +535,9 @@ class TcnGln(torch.autograd.Function):
         dil = (ctypes.c_int * nb)(*dilations)
         lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms), 1,
                  M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
-        # our own buffers, written once and read once by backward: plain attributes (no version counters needed)
+        # our own buffers, written once and read once by backward: plain attributes (released as soon as they are consumed)
         ctx.acts = (x0, xs, h1s, ds, ms)
-        ctx.params = params
+        ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
         ctx.cfg = (K, dil, nb, causal, P)
         ctx.sinks = tuple(_sink(p) for p in params)
         return xs[nb - 1]
@@ -548,7 +548,7 @@ class TcnGln(torch.autograd.Function):
             raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
                            "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
         x0, xs, h1s, ds, ms = ctx.acts
-        params = ctx.params
+        params = ctx.saved_tensors
         K, dil, nb, causal, P = ctx.cfg
         dout = _c(dout)
         _, M, B, Kp = xs.shape
@@ -636,7 +636,7 @@ class TcnCln(torch.autograd.Function):
         lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]), _p(hs[3]), _p(st), 1,
                  M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
         ctx.acts = (x0, xs, hs, st)
-        ctx.params = params
+        ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
         ctx.cfg = (K, dil, nb, causal, P)
         ctx.sinks = tuple(_sink(p) for p in params)
         return xs[nb - 1]
@@ -647,7 +647,7 @@ class TcnCln(torch.autograd.Function):
             raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
                            "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
         x0, xs, hs, st = ctx.acts
-        params = ctx.params
+        params = ctx.saved_tensors
         K, dil, nb, causal, P = ctx.cfg
         dout = _c(dout)
         _, M, B, Kp = xs.shape
