@@ -41,6 +41,8 @@ def apply(cfg):
             ops._COMPOSITE = bool(int(v))
         elif k == "side":
             ops._SIDE_ENABLED = bool(int(v))
+        elif k == "fwd_dual":
+            ops._FWD_DUAL = bool(int(v))
         elif k == "cln_side":
             ops._CLN_SIDE = bool(int(v))
         else:

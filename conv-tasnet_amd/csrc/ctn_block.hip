@@ -159,7 +159,7 @@ size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* ds, float* ms, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
     CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && workspace, "ctn_tcn_gln_fwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_fwd: bad sizes");
     const FwdWs w = fwd_ws(M, B, H, Kp, nblocks);
@@ -170,42 +170,56 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     double* const st1 = (double*)((char*)workspace + w.st1);
     double* const st2 = (double*)((char*)workspace + w.st2);
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
-    // the weight operand of both 1x1 convolutions of every block, prepared once: bf16 piece fragments (b3 arithmetic) or
+    // the weight operand of both 1x1 convolutions of every block, prepared once: bf16 piece fragments (split-bf16 arithmetics) or
     // [I, O] fp32 copies (16-byte LDS row writes instead of the transposing scatter); two launches for the whole stack
     char* const wreg = (char*)workspace + w.wt;
     const size_t slot = wslot_bytes(B, H);
-    int tw1 = 0, tw2 = 0;
+    int tw1 = 0, tw2 = 0, rc;
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
     }
-    {
-        int rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream);
-        if (rc) return rc;
-    }
-    const float* x = x0;
+    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream))) return rc;
+    // Two chains: the forward pass of a block is three strictly dependent kernels (K1 -> statistics -> K2 -> statistics -> K3) with
+    // nothing beside them, so the fill and epilogue of every GEMM and the whole HBM-bound depthwise kernel run with the matrix
+    // cores idle.  Utterances are independent (gLN statistics are per utterance): with side_stream the batch is cut in two halves
+    // that run the same chain on two streams, so that one half's HBM-bound phases sit beside the other half's MFMA phases.  Every
+    // kernel computes utterance by utterance, so the values are bitwise those of the single chain.
+    const int nch = (side_stream != nullptr && M >= 2) ? 2 : 1;
+    const int m0c[2] = {0, M / 2}, mcc[2] = {nch == 2 ? M / 2 : M, M - M / 2};
+    void* const sts[2] = {stream, side_stream};
+    if (nch == 2 && (rc = ctn_stream_order(stream, side_stream))) return rc;        // x0 and the weight operands are ready
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
-        for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
         const float* const w1t = (const float*)(wreg + (size_t)(2 * i) * slot);
         const float* const w2t = (const float*)(wreg + (size_t)(2 * i + 1) * slot);
         // save = 0 (inference): one h1 / d slot and two ping-pong x slots; save = 1: a slot per block for the backward pass
+        const float* const xin = i == 0 ? x0 : xs + (save ? (size_t)(i - 1) : (size_t)((i - 1) & 1)) * xsz;
         float* const h1 = h1s + (save ? (size_t)i * hsz : 0);
         float* const d = ds + (save ? (size_t)i * hsz : 0);
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const ms1 = ms + ((size_t)(save ? i : 0) * 2 + 0) * M * 2;
         float* const ms2 = ms + ((size_t)(save ? i : 0) * 2 + 1) * M * 2;
-        int rc = PROBED(F_K1, stream, ctn_pw_gemm(w1t, x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             p[P_A1], st1, 0, stream));
-        if (rc) return rc;
-        rc = PROBED(F_K2, stream, ctn_dw_fwd(h1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, st1, w.np1, p[P_G1], p[P_B1], p[P_A1], ms1,
-                        p[P_A2], st2, stream));
-        if (rc) return rc;
-        rc = PROBED(F_K3, stream, ctn_pw_gemm(w2t, d, out, M, B, H, K, Kp, tw2, st2, H, p[P_G2], p[P_B2], p[P_A2], ms2, x, nullptr, nullptr, 0,
-                         stream));
-        if (rc) return rc;
-        x = out;
+        for (int step = 0; step < 3; ++step)             // issue K1 of both chains, then K2 of both, then K3 of both: both queues stay fed
+            for (int c = 0; c < nch; ++c) {
+                const int m0 = m0c[c], Mc = mcc[c];
+                void* const st = sts[c];
+                const size_t xo = (size_t)m0 * B * Kp, ho = (size_t)m0 * H * Kp;
+                double* const s1 = st1 + (size_t)m0 * w.np1 * 2;
+                double* const s2 = st2 + (size_t)m0 * H * 2;
+                if (step == 0)
+                    rc = PROBED(F_K1, st, ctn_pw_gemm(w1t, xin + xo, h1 + ho, Mc, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                      p[P_A1], s1, 0, st));
+                else if (step == 1)
+                    rc = PROBED(F_K2, st, ctn_dw_fwd(h1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, s1, w.np1, p[P_G1], p[P_B1], p[P_A1],
+                                                     ms1 + 2 * m0, p[P_A2], s2, st));
+                else
+                    rc = PROBED(F_K3, st, ctn_pw_gemm(w2t, d + ho, out + xo, Mc, B, H, K, Kp, tw2, s2, H, p[P_G2], p[P_B2], p[P_A2], ms2 + 2 * m0, xin + xo,
+                                                      nullptr, nullptr, 0, st));
+                if (rc) return rc;
+            }
     }
+    if (nch == 2 && (rc = ctn_stream_order(side_stream, stream))) return rc;
     return CTN_OK;
 }
 
@@ -336,7 +350,7 @@ size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks
 int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
     CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && workspace, "ctn_tcn_cln_fwd: null pointer");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_fwd: bad sizes");
     if (workspace_bytes < ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nblocks)) {
@@ -350,23 +364,40 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
     for (int i = 0; i < nblocks; ++i)
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(params[(size_t)i * NPARAM + j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
     if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream))) return rc;
-    const float* x = x0;
+    // two half-batch chains on two streams, as in ctn_tcn_gln_fwd (cLN statistics are per frame of one utterance)
+    const int nch = (side_stream != nullptr && M >= 2) ? 2 : 1;
+    const int m0c[2] = {0, M / 2}, mcc[2] = {nch == 2 ? M / 2 : M, M - M / 2};
+    void* const sts[2] = {stream, side_stream};
+    if (nch == 2 && (rc = ctn_stream_order(stream, side_stream))) return rc;
     for (int i = 0; i < nblocks; ++i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         const size_t s = save ? (size_t)i : 0;
+        const float* const xin = i == 0 ? x0 : xs + (save ? (size_t)(i - 1) : (size_t)((i - 1) & 1)) * xsz;
         float* const h1 = h1s + s * hsz; float* const n1 = n1s + s * hsz; float* const d = ds + s * hsz; float* const n2 = n2s + s * hsz;
         float* const out = xs + (save ? (size_t)i : (size_t)(i & 1)) * xsz;
         float* const stb = st + s * 4 * ssz;
-        if ((rc = PROBED(F_K1, stream, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i) * slot), x, h1, M, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, 0, stream)))) return rc;
-        if ((rc = PROBED(F_CLN_FWD, stream, ctn_cln_fwd(h1, n1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], stream)))) return rc;
-        if ((rc = PROBED(F_K2, stream, ctn_dw_fwd(n1, d, p[P_D], M, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, stream)))) return rc;
-        if ((rc = PROBED(F_CLN_FWD, stream, ctn_cln_fwd(d, n2, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], stream)))) return rc;
-        if ((rc = PROBED(F_K3, stream, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i + 1) * slot), n2, out, M, B, H, K, Kp, tw2, nullptr, 0, nullptr, nullptr,
-                              nullptr, nullptr, x, nullptr, nullptr, 0, stream)))) return rc;
-        x = out;
+        for (int step = 0; step < 5; ++step)
+            for (int c = 0; c < nch; ++c) {
+                const int m0 = m0c[c], Mc = mcc[c];
+                void* const sc = sts[c];
+                const size_t xo = (size_t)m0 * B * Kp, ho = (size_t)m0 * H * Kp, so = (size_t)m0 * Kp;
+                if (step == 0)
+                    rc = PROBED(F_K1, sc, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i) * slot), xin + xo, h1 + ho, Mc, H, B, K, Kp, tw1, nullptr, 0, nullptr,
+                                                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sc));
+                else if (step == 1)
+                    rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(h1 + ho, n1 + ho, stb + so, stb + ssz + so, Mc, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], sc));
+                else if (step == 2)
+                    rc = PROBED(F_K2, sc, ctn_dw_fwd(n1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr,
+                                                     nullptr, nullptr, nullptr, sc));
+                else if (step == 3)
+                    rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(d + ho, n2 + ho, stb + 2 * ssz + so, stb + 3 * ssz + so, Mc, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], sc));
+                else
+                    rc = PROBED(F_K3, sc, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i + 1) * slot), n2 + ho, out + xo, Mc, B, H, K, Kp, tw2, nullptr, 0,
+                                                      nullptr, nullptr, nullptr, nullptr, xin + xo, nullptr, nullptr, 0, sc));
+                if (rc) return rc;
+            }
     }
+    if (nch == 2 && (rc = ctn_stream_order(side_stream, stream))) return rc;
     return CTN_OK;
 }
 

@@ -484,6 +484,14 @@ def _bucket_ranges(nb, direct):
 NPARAM = 9       # per block: w1, a1, g1, b1, D, a2, g2, b2, w2  (order of include/ctn_hip.h)
 
 
+_FWD_DUAL = os.environ.get("CTN_FWD_DUAL", "1") != "0"      # forward of the gLN stack as two half-batch chains on two streams
+
+
+def _fwd_side(dev):
+    """Second stream for the forward pass of the composite stack (0 = one chain)."""
+    return _side_stream(dev).cuda_stream if (_SIDE_ENABLED and _FWD_DUAL) else 0
+
+
 def composite_enabled():
     return _COMPOSITE
 
@@ -507,7 +515,7 @@ def tcn_gln_infer(x0, K, dilations, causal, params):
     ws = _workspace(nbytes, dev, "tcn_fwd")
     dil = (ctypes.c_int * nb)(*dilations)
     lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1), _p(d), _p(ms), 0,
-             M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+             M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
     return xs[(nb - 1) & 1]
 
 
@@ -534,7 +542,7 @@ class TcnGln(torch.autograd.Function):
         ws = _workspace(nbytes, dev, "tcn_fwd")
         dil = (ctypes.c_int * nb)(*dilations)
         lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms), 1,
-                 M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+                 M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
         # our own buffers, written once and read once by backward: plain attributes (released as soon as they are consumed)
         ctx.acts = (x0, xs, h1s, ds, ms)
         ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
@@ -607,7 +615,7 @@ def tcn_cln_infer(x0, K, dilations, causal, params):
     ws = _workspace(nbytes, dev, "tcn_cln_fwd")
     dil = (ctypes.c_int * nb)(*dilations)
     lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h[0]), _p(h[1]), _p(h[2]), _p(h[3]), _p(st), 0,
-             M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+             M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
     return xs[(nb - 1) & 1]
 
 
@@ -634,7 +642,7 @@ class TcnCln(torch.autograd.Function):
         ws = _workspace(nbytes, dev, "tcn_cln_fwd")
         dil = (ctypes.c_int * nb)(*dilations)
         lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]), _p(hs[3]), _p(st), 1,
-                 M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream())
+                 M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
         ctx.acts = (x0, xs, hs, st)
         ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
         ctx.cfg = (K, dil, nb, causal, P)

@@ -172,6 +172,9 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
  *     h1s [nblocks][M,H,Kp]  first 1x1 outputs,  ds [nblocks][M,H,Kp] depthwise outputs,
  *     ms  [nblocks][2][M][2] (mean, rstd) of the two gLNs.
  *     save = 0 (inference): xs needs 2 slots, h1s / ds / ms one slot each; the output is xs[(nblocks-1) & 1].
+ *   forward with side_stream != NULL and M >= 2: the batch runs as two half-batch chains on the two streams (utterances are
+ *     independent; one half's HBM-bound phases overlap the other half's MFMA phases); same values bit for bit; on return `stream`
+ *     is ordered after both.
  *   backward: dout [M,B,Kp] gradient of the stack's output; dxs [nblocks][M,B,Kp] receives the gradient of every
  *     block's input (dxs[0] = gradient w.r.t. x0); dn1s [nblocks][M,H,Kp] scratch (one slot per block, read by the
  *     weight-gradient stream).  side_stream != NULL: weight-gradient GEMMs and the fixed-order parameter-gradient sums go
@@ -184,7 +187,7 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* ds, float* ms, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp, int nblocks);
 int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
                     const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
@@ -209,7 +212,7 @@ int ctn_probe_read(int* fam, float* us, int cap);
 int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
                     float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks);
 int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
                     const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
