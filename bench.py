@@ -226,13 +226,22 @@ def family_table(probe, stack, cfg, K, steps):
         12: ("cln_bwd (input gradient + parameter-gradient partials)", None, t4 * 3 * H),
         13: ("dw_bwd_taps (depthwise weight gradient sums)", None, 0.0),
     }
+    # the forward families run as `chains` half-batch launches per block (two streams): each launch does 1 / chains of the work
+    nblk = c["X"] * c["R"]
+    per_fid = {}
+    for fid, _ in stack:
+        per_fid[fid] = per_fid.get(fid, 0) + 1
     for fid, us in stack:
         name, shape, nbytes = STACK[fid]
+        per_block = per_fid[fid] / float(steps * nblk)
+        chains = 2.0 if (fid in (0, 1, 2, 11) and abs(per_block / (2.0 if fid == 11 else 1.0) - 2.0) < 1e-6) else 1.0
+        if chains > 1.0 and "half-batch" not in name:
+            name += " [two half-batch launches per block]"
         f = fams.setdefault(name, {"bound": "mfma" if shape else "hbm", "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": "stack"})
         f["us"].append(us)
-        f["bytes"] += nbytes
+        f["bytes"] += nbytes / chains
         if shape:
-            f["flops"] += 2.0 * shape[1] * shape[2] * K * shape[0]
+            f["flops"] += 2.0 * shape[1] * shape[2] * K * shape[0] / chains
             small = (shape[1] < 32 or shape[2] < 32) if fid in (4, 8) else shape[1] < 64
             f["b3"] += int(b3 and not small)
     for name, a, e0, e1 in probe:
