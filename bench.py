@@ -36,8 +36,8 @@ PEAK_HBM_GBS = 8000.0          # same guide, HBM3E peak
 ARITH = {"name": "b6"}         # GEMM arithmetic of this run (--arith): "b6" = 6 bf16 MFMAs per product step (three bf16 pieces per
                                # fp32 operand: fp32-faithful products, the library default), "fp32" = fp32 MFMA, "b3" = 3 bf16 MFMAs
                                # (two pieces: ~16-bit products, opt-in, NOT reference precision)
-ARITH_IDS = {"fp32": 0, "b3": 1, "b6": 2}
-MFMA_PER_STEP = {"b3": 3, "b6": 6}
+ARITH_IDS = {"fp32": 0, "b3": 1, "b6": 2, "h3": 3}
+MFMA_PER_STEP = {"b3": 3, "b6": 6, "h3": 3}
 PER_GPU_BATCH = 8
 CONFIGS = {
     "paper": dict(model=dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2), norm_type="gLN", causal=False, T=32000, sr=8000,
@@ -337,7 +337,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="paper")
-    ap.add_argument("--arith", choices=["b6", "fp32", "b3"], default=os.environ.get("CTN_GEMM_ARITH", "b6"),
+    ap.add_argument("--arith", choices=["h3", "b6", "fp32", "b3"], default=os.environ.get("CTN_GEMM_ARITH", "h3"),
                     help="GEMM arithmetic: b6 = three bf16 pieces per fp32 operand, six bf16 MFMAs per product step (fp32-faithful "
                          "products; library default), fp32 = fp32-MFMA kernels, b3 = two pieces / three MFMAs (~16-bit products; "
                          "NOT reference precision, opt-in)")

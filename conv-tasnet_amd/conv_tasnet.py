@@ -481,7 +481,7 @@ class _GlnOnly(torch.autograd.Function):
         ops.lib.call("ctn_gln_bwd_sums", dout.data_ptr(), yp.data_ptr(), M, Ch, K, Kp, gamma.data_ptr(), one.data_ptr(),
                      ms.data_ptr(), sums.data_ptr(), pc.data_ptr(), ops._stream())
         ops.lib.call("ctn_gln_prelu_bwd", dout.data_ptr(), yp.data_ptr(), dy.data_ptr(), M, Ch, K, Kp, gamma.data_ptr(),
-                     one.data_ptr(), ms.data_ptr(), sums.data_ptr(), Ch, dap.data_ptr(), ops._stream())
+                     one.data_ptr(), ms.data_ptr(), sums.data_ptr(), Ch, dap.data_ptr(), 0, ops._stream())
         dgb = ops.reduce_mid(pc, 2, M, Ch)
         return dy, dgb[0].view_as(gamma), dgb[1].view_as(gamma), None
 

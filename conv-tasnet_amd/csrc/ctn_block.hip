@@ -72,19 +72,25 @@ inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 // operand (b3 arithmetic, ctn_split_b3_batch) -- the same bytes when H and B are multiples of 32.
 inline size_t wslot_bytes(int B, int H) {
     size_t n = (size_t)H * B * sizeof(float);
-    const size_t a = ctn_split_b3_bytes(H, B), b = ctn_split_b3_bytes(B, H);
+    const size_t a = ctn_split_b3_bytes(H, B), b = ctn_split_b3_bytes(B, H), c = ctn_split_h3_bytes(H, B), d = ctn_split_h3_bytes(B, H);
     if (a > n) n = a;
     if (b > n) n = b;
+    if (c > n) n = c;
+    if (d > n) n = d;
     return align256(n);
 }
 inline bool pieces(int R) { return ctn_gemm_arith() != 0 && R >= 64; }      // the rule of ctn_pw_gemm(trans_w = 2)
+// h3 arithmetic (include/ctn_hip.h): the six GEMMs of every block on the ctn_*_h3 entry points, operand ranges tracked by the
+// producing kernels.  Both layer widths must qualify; otherwise the stack runs as b6.
+inline bool use_h3(int B, int H) { return ctn_gemm_arith() == 3 && B >= 64 && H >= 64; }
 
 // Weight operands of every block, prepared once per call into region [nblocks][2 slots]: slot 0 for the GEMM with H output
 // rows, slot 1 for the one with B output rows.  fwd: (w1 -> H rows, w2 -> B rows) as stored; bwd: (w2 -> H rows, w1 -> B rows)
 // transposed.  tw_h / tw_b receive the trans_w code of ctn_pw_gemm for the prepared operand (2 pieces, 1 fp32 [I, O] copy;
 // backward without pieces uses the stored matrices: no copy, code 1).
+// h3: pieces from ctn_split_h3_batch (code 3), and gb [nblocks][2] receives {max |gamma2|, max |beta2|} of every block.
 int prepare_weights(const void* const* params, int nblocks, int B, int H, bool backward, char* region, size_t slot,
-                    int* tw_h, int* tw_b, void* stream) {
+                    int* tw_h, int* tw_b, bool h3, float* gb, void* stream) {
     std::vector<const void*> src(nblocks);
     std::vector<void*> dst(nblocks);
     int rc;
@@ -96,7 +102,10 @@ int prepare_weights(const void* const* params, int nblocks, int B, int H, bool b
             dst[i] = region + ((size_t)2 * i + half) * slot;
         }
         int* const tw = half == 0 ? tw_h : tw_b;
-        if (pieces(R)) {
+        if (h3) {
+            if ((rc = PROBED(F_PREP, stream, ctn_split_h3_batch(src.data(), dst.data(), nblocks, R, Cn, backward ? 1 : 0, stream)))) return rc;
+            *tw = 3;
+        } else if (pieces(R)) {
             if ((rc = PROBED(F_PREP, stream, ctn_split_b3_batch(src.data(), dst.data(), nblocks, R, Cn, backward ? 1 : 0, stream)))) return rc;
             *tw = 2;
         } else if (!backward) {
@@ -106,11 +115,22 @@ int prepare_weights(const void* const* params, int nblocks, int B, int H, bool b
             *tw = -1;       // use the stored matrix (trans_w = 1)
         }
     }
+    if (h3) {
+        std::vector<const void*> gsrc(2 * (size_t)nblocks);
+        std::vector<void*> gdst(2 * (size_t)nblocks);
+        for (int i = 0; i < nblocks; ++i) {
+            gsrc[2 * i] = ((const void* const*)(params + (size_t)i * NPARAM))[P_G2];
+            gsrc[2 * i + 1] = ((const void* const*)(params + (size_t)i * NPARAM))[P_B2];
+            gdst[2 * i] = gb + 2 * i;
+            gdst[2 * i + 1] = gb + 2 * i + 1;
+        }
+        if ((rc = PROBED(F_PREP, stream, ctn_absmax_batch(gsrc.data(), gdst.data(), 2 * nblocks, H, stream)))) return rc;
+    }
     return CTN_OK;
 }
 
 struct FwdWs {
-    size_t st1, st2, wt, total;
+    size_t st1, st2, wt, gb, total;
     int np1;
 };
 FwdWs fwd_ws(int M, int B, int H, int Kp, int nblocks) {
@@ -119,12 +139,13 @@ FwdWs fwd_ws(int M, int B, int H, int Kp, int nblocks) {
     w.st1 = 0;
     w.st2 = align256((size_t)M * w.np1 * 2 * sizeof(double));
     w.wt = w.st2 + align256((size_t)M * H * 2 * sizeof(double));
-    w.total = w.wt + (size_t)nblocks * 2 * wslot_bytes(B, H);                            // [nblocks][w1 operand | w2 operand]
+    w.gb = w.wt + (size_t)nblocks * 2 * wslot_bytes(B, H);                               // [nblocks][w1 operand | w2 operand]
+    w.total = w.gb + align256((size_t)nblocks * 2 * sizeof(float));                      // h3: {max |gamma2|, max |beta2|} per block
     return w;
 }
 
 struct BwdWs {
-    size_t dn2, s2p, s1p, pc, da1p, slab, wp, total, pc_slot, da1p_slot, s1p_slot;
+    size_t dn2, s2p, s1p, pc, da1p, slab, wp, gb, amax, total, pc_slot, da1p_slot, s1p_slot;
     size_t slab_bytes;
     int np2;
 };
@@ -145,6 +166,8 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.slab_bytes = s1 > s2 ? s1 : s2;
     w.slab = o; o += align256(w.slab_bytes);
     w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);         // [nblocks][w2 operand (H rows) | w1 operand (B rows)], b3 pieces
+    w.gb = o; o += align256((size_t)nblocks * 2 * sizeof(float));   // h3: {max |gamma2|, max |beta2|} per block
+    w.amax = o; o += align256((size_t)nblocks * 2 * M * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block and utterance
     w.total = o;
     return w;
 }
@@ -157,10 +180,12 @@ size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) { ret
 size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks) { return bwd_ws(M, B, H, Kp, P, nblocks).total; }
 
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
-                    float* xs, float* h1s, float* ds, float* ms, int save,
+                    float* xs, float* h1s, float* ds, float* ms, unsigned* amax, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
     CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && workspace, "ctn_tcn_gln_fwd: null pointer");
+    const bool h3 = use_h3(B, H);
+    CTN_REQUIRE(!h3 || amax, "ctn_tcn_gln_fwd: the h3 arithmetic needs the amax array");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_fwd: bad sizes");
     const FwdWs w = fwd_ws(M, B, H, Kp, nblocks);
     if (workspace_bytes < w.total) {
@@ -179,7 +204,15 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(p[j], "ctn_tcn_gln_fwd: block %d parameter %d is null", i, j);
     }
-    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream))) return rc;
+    float* const gb = (float*)((char*)workspace + w.gb);
+    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, h3, gb, stream))) return rc;
+    if (h3) {       // range tracking: every slot starts at 0; the stack's input is measured here, everything else by its producer
+        if (hipMemsetAsync(amax, 0, (size_t)nblocks * 2 * M * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+            ctn_set_error("ctn_tcn_gln_fwd: hipMemsetAsync failed");
+            return CTN_ERR_LAUNCH;
+        }
+        if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(x0, M, (long long)B * Kp, amax, stream)))) return rc;
+    }
     // Two chains: the forward pass of a block is three strictly dependent kernels (K1 -> statistics -> K2 -> statistics -> K3) with
     // nothing beside them, so the fill and epilogue of every GEMM and the whole HBM-bound depthwise kernel run with the matrix
     // cores idle.  Utterances are independent (gLN statistics are per utterance): with side_stream the batch is cut in two halves
@@ -207,12 +240,24 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
                 const size_t xo = (size_t)m0 * B * Kp, ho = (size_t)m0 * H * Kp;
                 double* const s1 = st1 + (size_t)m0 * w.np1 * 2;
                 double* const s2 = st2 + (size_t)m0 * H * 2;
-                if (step == 0)
+                unsigned* const ax = h3 ? amax + (size_t)(2 * i) * M + m0 : nullptr;        // max |x_in|, max |d| of this block
+                unsigned* const ad = h3 ? amax + (size_t)(2 * i + 1) * M + m0 : nullptr;
+                if (h3) {
+                    if (step == 0)
+                        rc = PROBED(F_K1, st, ctn_pw_gemm_h3(w1t, xin + xo, h1 + ho, Mc, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                             p[P_A1], s1, ax, nullptr, nullptr, st));
+                    else if (step == 1)
+                        rc = PROBED(F_K2, st, ctn_dw_fwd(h1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, s1, w.np1, p[P_G1], p[P_B1], p[P_A1],
+                                                         ms1 + 2 * m0, p[P_A2], s2, ad, st));
+                    else
+                        rc = PROBED(F_K3, st, ctn_pw_gemm_h3(w2t, d + ho, out + xo, Mc, B, H, K, Kp, s2, H, p[P_G2], p[P_B2], p[P_A2], ms2 + 2 * m0, xin + xo,
+                                                             nullptr, nullptr, ad, gb + 2 * i, i + 1 < nblocks ? amax + (size_t)(2 * i + 2) * M + m0 : nullptr, st));
+                } else if (step == 0)
                     rc = PROBED(F_K1, st, ctn_pw_gemm(w1t, xin + xo, h1 + ho, Mc, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                       p[P_A1], s1, 0, st));
                 else if (step == 1)
                     rc = PROBED(F_K2, st, ctn_dw_fwd(h1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, s1, w.np1, p[P_G1], p[P_B1], p[P_A1],
-                                                     ms1 + 2 * m0, p[P_A2], s2, st));
+                                                     ms1 + 2 * m0, p[P_A2], s2, nullptr, st));
                 else
                     rc = PROBED(F_K3, st, ctn_pw_gemm(w2t, d + ho, out + xo, Mc, B, H, K, Kp, tw2, s2, H, p[P_G2], p[P_B2], p[P_A2], ms2 + 2 * m0, xin + xo,
                                                       nullptr, nullptr, 0, st));
@@ -224,12 +269,14 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
 }
 
 int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
-                    const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
+                    const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms, const unsigned* amax,
                     const float* dout, float* dxs, float* dn1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags) {
     CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && ds && ms && dout && dxs && dn1s && workspace,
                 "ctn_tcn_gln_bwd: null pointer");
+    const bool h3 = use_h3(B, H);
+    CTN_REQUIRE(!h3 || amax, "ctn_tcn_gln_bwd: the h3 arithmetic needs the forward pass's amax array");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_gln_bwd: bad sizes");
     const BwdWs w = bwd_ws(M, B, H, Kp, P, nblocks);
     if (workspace_bytes < w.total) {
@@ -250,13 +297,26 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     char* const wreg = ws + w.wp;
     const size_t slot = wslot_bytes(B, H);
     int twh = -1, twb = -1;
-    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, stream))) return rc;
+    float* const gb = (float*)(ws + w.gb);
+    unsigned* const amax_b = (unsigned*)(ws + w.amax);          // [nblocks][dy | dh1][M]
+    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, h3, gb, stream))) return rc;
+    if (h3) {
+        if (hipMemsetAsync(amax_b, 0, (size_t)nblocks * 2 * M * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+            ctn_set_error("ctn_tcn_gln_bwd: hipMemsetAsync failed");
+            return CTN_ERR_LAUNCH;
+        }
+        if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M, stream)))) return rc;
+    }
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
         const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
         const float* const h1 = h1s + (size_t)i * hsz;
         const float* const d = ds + (size_t)i * hsz;
+        const unsigned* const ax = h3 ? amax + (size_t)(2 * i) * M : nullptr;           // forward: max |x_in|, max |d|
+        const unsigned* const ad = h3 ? amax + (size_t)(2 * i + 1) * M : nullptr;
+        unsigned* const ady = amax_b + (size_t)(2 * i) * M;                             // backward: max |dy|, max |dh1|
+        unsigned* const adh = amax_b + (size_t)(2 * i + 1) * M;
         const float* const ms1 = ms + ((size_t)i * 2 + 0) * M * 2;
         const float* const ms2 = ms + ((size_t)i * 2 + 1) * M * 2;
         const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;   // gradient of this block's output
@@ -266,11 +326,13 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         float* const da1p = (float*)(ws + w.da1p + (size_t)i * w.da1p_slot);
         double* const s1p = (double*)(ws + w.s1p + (size_t)i * w.s1p_slot);
         // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
-        if (twh == 2) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
+        if (h3) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_h3(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, ady, stream));
+        else if (twh == 2) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         else rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         if (rc) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst));
+        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, ady, ad, gb + 2 * i, slab, w.slab_bytes, wst));
+        else rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst));
         if (rc) return rc;
         // gLN2 <- PReLU2 <- depthwise <- gLN1 output in one pass, then gLN1 + PReLU1 backward in place
         rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
@@ -279,12 +341,13 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         // gLN1' / PReLU1' backward in place (B4).  (Folding it into the operand prologues of its two consumers was built and
         // measured in round 2: 10.23 vs 10.13 ms per step with B4 as its own pass -- both GEMMs then read h1 as well.)
         const int n_da1 = M * H;
-        rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, stream));
+        rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, h3 ? adh : nullptr, stream));
         if (rc) return rc;
         // first 1x1; the weight gradient and the fixed-order sums of this block's parameter-gradient partials feed only the
         // optimiser: second stream
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         auto wgrad1 = [&]() -> int {
+            if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slab, w.slab_bytes, wst));
             return PROBED(F_B6, wst, ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
         };
         auto finalize = [&](void* st) -> int {
@@ -294,7 +357,9 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = wgrad1())) return rc;
             if ((rc = finalize(wst))) return rc;
         }
-        rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+        if (h3) rc = PROBED(F_B5, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i + 1) * slot, dn1, dx, M, B, H, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy,
+                         nullptr, nullptr, adh, nullptr, i > 0 ? amax_b + (size_t)(2 * i - 2) * M : nullptr, stream));
+        else rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
                          nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
         if (rc) return rc;
         if (!side_stream) {
@@ -363,7 +428,7 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
     int rc, tw1 = 0, tw2 = 0;
     for (int i = 0; i < nblocks; ++i)
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(params[(size_t)i * NPARAM + j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
-    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, stream))) return rc;
+    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, false, nullptr, stream))) return rc;
     // two half-batch chains on two streams, as in ctn_tcn_gln_fwd (cLN statistics are per frame of one utterance)
     const int nch = (side_stream != nullptr && M >= 2) ? 2 : 1;
     const int m0c[2] = {0, M / 2}, mcc[2] = {nch == 2 ? M / 2 : M, M - M / 2};
@@ -388,7 +453,7 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
                     rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(h1 + ho, n1 + ho, stb + so, stb + ssz + so, Mc, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], sc));
                 else if (step == 2)
                     rc = PROBED(F_K2, sc, ctn_dw_fwd(n1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr,
-                                                     nullptr, nullptr, nullptr, sc));
+                                                     nullptr, nullptr, nullptr, nullptr, sc));
                 else if (step == 3)
                     rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(d + ho, n2 + ho, stb + 2 * ssz + so, stb + 3 * ssz + so, Mc, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], sc));
                 else
@@ -428,7 +493,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     char* const wreg = ws + w.wp;
     const size_t slot = wslot_bytes(B, H);
     int twh = -1, twb = -1;
-    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, stream))) return rc;
+    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, false, nullptr, stream))) return rc;
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);

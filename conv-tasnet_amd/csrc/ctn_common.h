@@ -66,6 +66,32 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
     return r;
 }
 
+// Maximum of |v| over a block, merged into *dst (bit pattern of a non-negative float: unsigned order = float order; NaN
+// patterns compare above every number, so a NaN anywhere poisons the maximum, as it should).  max is exact and order-free:
+// the atomic keeps results bitwise reproducible.  `scratch` holds >= NT/64 doubles.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int NT>
+__device__ __forceinline__ void block_amax_atomic(float v, double* scratch, unsigned* dst) {
+    constexpr int NW = NT / 64;
+    unsigned b = __float_as_uint(fabsf(v));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
+    unsigned* const sc = reinterpret_cast<unsigned*>(scratch);
+    __syncthreads();  // scratch may still be read by a previous reduction
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned r = sc[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) r = r > sc[w] ? r : sc[w];
+        if (r != 0u) atomicMax(dst, r);
+    }
+}
+
 __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
 
 // Finalise (mean, rstd) of one utterance from [nparts][2] double partial (sum, sumsq).

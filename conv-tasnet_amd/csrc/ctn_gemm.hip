@@ -428,19 +428,21 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 
 int g_ctn_tile_override = -2;
 
-// GEMM arithmetic (ctn_gemm_b3.h): 2 = "b6" (default: three bf16 pieces per operand, six bf16 MFMAs, fp32 accumulation --
-// fp32-faithful products), 1 = "b3" (two pieces, three MFMAs: ~16-bit products, opt-in), 0 = fp32 MFMA (bit-exact fp32 FMA
-// chains).  CTN_GEMM_ARITH=b6|b3|fp32, ctn_tune("arith", 2|1|0).  Layers with fewer than 64 output rows (the decoder's basis
-// GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
+// GEMM arithmetic (ctn_gemm_b3.h): 3 = "h3" (default: the composite stacks run their GEMMs on two fp16 pieces per operand under
+// tracked power-of-two scales, three f16 MFMAs -- the ctn_*_h3 entry points; every other GEMM as b6), 2 = "b6" (three bf16 pieces
+// per operand, six bf16 MFMAs, fp32 accumulation), 1 = "b3" (two bf16 pieces, three MFMAs: ~16-bit products, opt-in), 0 = fp32
+// MFMA (bit-exact fp32 FMA chains).  CTN_GEMM_ARITH=h3|b6|b3|fp32, ctn_tune("arith", 3|2|1|0).  Layers with fewer than 64 output
+// rows (the decoder's basis GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
 static int g_arith = -1;
 static int arith_id() {
     if (g_arith < 0) {
         const char* e = getenv("CTN_GEMM_ARITH");
-        g_arith = (e && !strcmp(e, "fp32")) ? 0 : (e && !strcmp(e, "b3")) ? 1 : 2;
+        g_arith = (e && !strcmp(e, "fp32")) ? 0 : (e && !strcmp(e, "b3")) ? 1 : (e && !strcmp(e, "b6")) ? 2 : 3;
     }
     return g_arith;
 }
-static int arith_np() { return arith_id() == 0 ? 0 : arith_id() + 1; }       // pieces per operand (0: fp32 MFMA)
+// kernel arithmetic id (template parameter AR of ctn_gemm_b3.h) of the plain entry points: 0 fp32 MFMA, 2 b3, 3 b6 (also under h3)
+static int arith_np() { return arith_id() == 0 ? 0 : (arith_id() == 1 ? 2 : 3); }
 static bool b3_fwd(int R) { return arith_id() != 0 && R >= 64; }
 static bool b3_wgrad(int R, int Cn) { return arith_id() != 0 && R >= 32 && Cn >= 32; }
 
@@ -653,7 +655,7 @@ int ctn_tune(const char* key, int value) {
     if (!key) return CTN_ERR_ARG;
     if (!strcmp(key, "pw_tile") && value >= -1 && value <= 3) g_ctn_tile_override = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
-    else if (!strcmp(key, "arith") && value >= 0 && value <= 2) g_arith = value;
+    else if (!strcmp(key, "arith") && value >= 0 && value <= 3) g_arith = value;
     else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 2) g_ctn_b3_tile = value;
     else if (!strcmp(key, "b3_tile_k3") && value >= 0 && value <= 2) g_ctn_b3_tile_k3 = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
@@ -717,6 +719,107 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     const long long n = (long long)R * Cn;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(n / 4, NT)), block, 0, st, a.slab, nsplit, n, dW);   // R, Cn multiples of 4
     CTN_CHECK_LAUNCH("ctn_pw_wgrad/reduce");
+    return CTN_OK;
+}
+
+// ---- h3 arithmetic: explicit entry points (independent of ctn_tune("arith")); see include/ctn_hip.h ------------------------------
+size_t ctn_split_h3_bytes(int R, int Cn) { return ctn_b3_planes_bytes(4, R, Cn); }
+
+int ctn_split_h3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream) {
+    CTN_REQUIRE(src && dst && n > 0 && R > 0 && Cn > 0 && (R * Cn) % 4 == 0, "ctn_split_h3_batch: bad arguments");
+    for (int i = 0; i < n; ++i) CTN_REQUIRE(src[i] && dst[i] && aligned16(src[i]) && aligned16(dst[i]), "ctn_split_h3_batch: matrix %d: null or unaligned pointer", i);
+    ctn_b3_launch_split(4, src, dst, n, R, Cn, k_major, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_split_h3_batch");
+    return CTN_OK;
+}
+
+int ctn_absmax_batch(const void* const* src, void* const* dst, int n, int len, void* stream) {
+    CTN_REQUIRE(src && dst && n > 0 && len > 0, "ctn_absmax_batch: bad arguments");
+    for (int i = 0; i < n; ++i) CTN_REQUIRE(src[i] && dst[i] && aligned16(src[i]), "ctn_absmax_batch: array %d: null or unaligned pointer", i);
+    ctn_b3_launch_absmax(src, dst, 0, n, len, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_absmax_batch");
+    return CTN_OK;
+}
+
+int ctn_absmax_rows(const float* x, int M, long long n, unsigned* amax, void* stream) {
+    CTN_REQUIRE(x && amax && M > 0 && n > 0 && n % 4 == 0 && aligned16(x), "ctn_absmax_rows: bad arguments");
+    int nb = (int)ctn_cdivll(n, 1024 * 8);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3(nb, M), dim3(256), 0, (hipStream_t)stream, x, n, amax);
+    CTN_CHECK_LAUNCH("ctn_absmax_rows");
+    return CTN_OK;
+}
+
+int ctn_pw_gemm_h3(const void* Wp, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
+                   const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+                   const float* pro_alpha, float* pro_ms_out, const float* residual, const float* epi_alpha, double* epi_part,
+                   const unsigned* x_amax, const float* pro_gbmax, unsigned* out_amax, void* stream) {
+    int rc = check_common("ctn_pw_gemm_h3", (const float*)Wp, X, Out, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(R >= 64, "ctn_pw_gemm_h3: R >= 64");
+    CTN_REQUIRE(x_amax, "ctn_pw_gemm_h3: the operand's maximum is required");
+    CTN_REQUIRE(!(residual && epi_part), "ctn_pw_gemm_h3: residual and stats epilogues are exclusive");
+    CTN_REQUIRE(!pro_part || (pro_gamma && pro_beta && pro_alpha && pro_nparts > 0 && pro_gbmax), "ctn_pw_gemm_h3: incomplete prologue arguments");
+    CTN_REQUIRE(!epi_part || epi_alpha, "ctn_pw_gemm_h3: stats epilogue needs alpha");
+    CTN_REQUIRE(!residual || aligned16(residual), "ctn_pw_gemm_h3: residual must be 16-byte aligned");
+    CTN_REQUIRE(!out_amax || residual, "ctn_pw_gemm_h3: out_amax comes with the residual epilogue");
+    PwArgs a{};
+    a.W = (const float*)Wp; a.X = X; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
+    a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
+    a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
+    a.x_amax = x_amax; a.pro_gbmax = pro_gbmax; a.out_amax = out_amax;
+    ctn_b3_launch_fwd(4, a, 2, pro_part != nullptr, residual != nullptr, epi_part != nullptr, false, false, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_gemm_h3");
+    return CTN_OK;
+}
+
+int ctn_pw_dgrad_gln_h3(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                        const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                        const unsigned* g_amax, void* stream) {
+    int rc = check_common("ctn_pw_dgrad_gln_h3", (const float*)Wp, dOut, dN, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(y && gamma && alpha && ms && sums_part && g_amax, "ctn_pw_dgrad_gln_h3: null pointer");
+    CTN_REQUIRE(aligned16(y) && R >= 64, "ctn_pw_dgrad_gln_h3: y must be 16-byte aligned, R >= 64");
+    PwArgs a{};
+    a.W = (const float*)Wp; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
+    a.x_amax = g_amax;
+    ctn_b3_launch_fwd(4, a, 2, false, false, false, false, true, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln_h3");
+    return CTN_OK;
+}
+
+size_t ctn_pw_wgrad_h3_workspace(int M, int R, int Cn, int Kp) {
+    int chunk, cpm;
+    ctn_b3_wgrad_plan(M, R, Cn, Kp, &chunk, &cpm);
+    return (size_t)M * cpm * R * Cn * sizeof(float);
+}
+
+int ctn_pw_wgrad_h3(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                    const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                    const unsigned* g_amax, const unsigned* x_amax, const float* pro_gbmax,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("ctn_pw_wgrad_h3", dW, X, (const float*)dOut, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(R >= 32 && Cn >= 32, "ctn_pw_wgrad_h3: both sides >= 32");
+    CTN_REQUIRE(g_amax && x_amax, "ctn_pw_wgrad_h3: the operands' maxima are required");
+    CTN_REQUIRE(!pro_ms || (pro_gamma && pro_beta && pro_alpha && pro_gbmax), "ctn_pw_wgrad_h3: incomplete prologue arguments");
+    WgArgs a{};
+    a.dOut = dOut; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.pro_gamma = pro_gamma; a.pro_beta = pro_beta; a.pro_alpha = pro_alpha; a.pro_ms = pro_ms;
+    a.g_amax = g_amax; a.x_amax = x_amax; a.pro_gbmax = pro_gbmax;
+    ctn_b3_wgrad_plan(M, R, Cn, Kp, &a.chunk, &a.chunks_per_m);
+    const size_t need = (size_t)M * a.chunks_per_m * R * Cn * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) {
+        ctn_set_error("ctn_pw_wgrad_h3: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return CTN_ERR_WORKSPACE;
+    }
+    const int ns = ctn_b3_launch_wgrad(4, a, pro_ms != nullptr, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_wgrad_h3");
+    const long long nn = (long long)R * Cn;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);
+    CTN_CHECK_LAUNCH("ctn_pw_wgrad_h3/reduce");
     return CTN_OK;
 }
 }  // extern "C"

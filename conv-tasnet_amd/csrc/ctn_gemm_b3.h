@@ -33,29 +33,78 @@ namespace {
 constexpr int XK = 32;               // contraction steps per k-tile (two MFMA steps of depth 16)
 constexpr int XPA = XK + 8;          // row pitch of a row-major piece plane in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
 
+// Arithmetic ids of the kernels below (template parameter AR): 2 = b3, 3 = b6 (NP = AR bf16 pieces), 4 = h3 (two fp16 pieces).
+template <int AR> struct Ar { static constexpr int NP = AR; static constexpr bool F16 = false; };
+template <> struct Ar<4> { static constexpr int NP = 2; static constexpr bool F16 = true; };
+
 // four consecutive fp32 -> NP bf16x4 pieces, most significant first (round-to-nearest-even each time; the differences are exact).
 // Written on packed pairs: one v_cvt_pk_bf16_f32 per pair and piece, the bf16 -> fp32 widening as a shift / mask of the packed
 // register -- 5.5 VALU instructions per element for three pieces (the element-wise form compiled to 7.5).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, bf16x2v));
 }
 __device__ __forceinline__ float pk_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float pk_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-template <int NP>
-__device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[NP]) {
-    static_assert(NP == 2 || NP == 3, "two or three pieces");
-    const unsigned h0 = pk_bf16(v.x, v.y), h1 = pk_bf16(v.z, v.w);
-    const float r0 = v.x - pk_lo(h0), r1 = v.y - pk_hi(h0), r2 = v.z - pk_lo(h1), r3 = v.w - pk_hi(h1);
-    const unsigned m0 = pk_bf16(r0, r1), m1 = pk_bf16(r2, r3);
-    q[0] = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
-    q[1] = __builtin_bit_cast(bf16x4, u32x2v{m0, m1});
-    if constexpr (NP == 3) {
-        const unsigned l0 = pk_bf16(r0 - pk_lo(m0), r1 - pk_hi(m0)), l1 = pk_bf16(r2 - pk_lo(m1), r3 - pk_hi(m1));
-        q[2] = __builtin_bit_cast(bf16x4, u32x2v{l0, l1});
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {          // round-to-nearest-even (v_cvt_pk_f16_f32)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{a, b}, f16x2v));
+}
+// `s` (h3 only): the operand's power-of-two scale.  The 16-bit containers are declared bf16x4 / bf16x8 for every arithmetic
+// (LDS traffic and fragment moves do not look at the format); only the split and the MFMA know what the bits mean.
+template <int AR>
+__device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[Ar<AR>::NP], float s) {
+    static_assert(AR == 2 || AR == 3 || AR == 4, "b3, b6 or h3");
+    if constexpr (Ar<AR>::F16) {
+        // a s = a0 + a1 + r:  a0 = f16_rne(a s), a1 = f16_rne(a s - a0) (the difference is exact in fp32), |r| <= 2^-24 |a s| as
+        // long as a1 is a normal fp16 number, |r| <= 2^-25 (half an fp16 subnormal step) below that
+        const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+        const unsigned h0 = pk_f16(x0, x1), h1 = pk_f16(x2, x3);
+        const f32x2v w0 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h0), f32x2v);
+        const f32x2v w1 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h1), f32x2v);
+        const unsigned m0 = pk_f16(x0 - w0.x, x1 - w0.y), m1 = pk_f16(x2 - w1.x, x3 - w1.y);
+        q[0] = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
+        q[1] = __builtin_bit_cast(bf16x4, u32x2v{m0, m1});
+    } else {
+        (void)s;
+        const unsigned h0 = pk_bf16(v.x, v.y), h1 = pk_bf16(v.z, v.w);
+        const float r0 = v.x - pk_lo(h0), r1 = v.y - pk_hi(h0), r2 = v.z - pk_lo(h1), r3 = v.w - pk_hi(h1);
+        const unsigned m0 = pk_bf16(r0, r1), m1 = pk_bf16(r2, r3);
+        q[0] = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
+        q[1] = __builtin_bit_cast(bf16x4, u32x2v{m0, m1});
+        if constexpr (AR == 3) {
+            const unsigned l0 = pk_bf16(r0 - pk_lo(m0), r1 - pk_hi(m0)), l1 = pk_bf16(r2 - pk_lo(m1), r3 - pk_hi(m1));
+            q[2] = __builtin_bit_cast(bf16x4, u32x2v{l0, l1});
+        }
     }
+}
+
+// ---- h3 scales.  An operand with |x| <= bound is multiplied by 2^e, e = h3_exp(bound), so that |x| 2^e < 2^14 (fp16 holds
+// 65504: a factor 4 of headroom for the rounding of the bound itself).  Elements down to 2^-17 of the bound keep both pieces
+// normal (relative error 2^-24); smaller ones lose relative precision gracefully, absolute error <= 2^-39 of the bound.
+__device__ __forceinline__ int h3_exp(float bound) {          // bound >= 0 (NaN / inf: the scaled operand overflows to inf -> NaN)
+    const int ex = (int)((__float_as_uint(bound) >> 23) & 0xffu);       // bound < 2^(ex - 126)
+    const int e = 140 - ex;
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__device__ __forceinline__ float h3_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }   // |e| <= 126
+// bound of gamma ((prelu(x) - mean) rstd) + beta over an utterance whose stored values satisfy |x| <= amax
+__device__ __forceinline__ float h3_pro_bound(float amax, float alpha, float mean, float rstd, const float* gbmax) {
+    const float pa = fmaxf(1.f, fabsf(alpha)) * amax;
+    return gbmax[0] * fabsf(rstd) * (pa + fabsf(mean)) + gbmax[1];
+}
+// acc *= 2^-(ea + eb), as two factors of about half the exponent each (every intermediate stays in range whenever the result does)
+template <int N>
+__device__ __forceinline__ void h3_unscale(f32x16 (&acc)[N], int ea, int eb) {
+    const int t = -(ea + eb), t1 = t / 2;
+    const float f1 = h3_pow2(t1), f2 = h3_pow2(t - t1);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = (acc[i][e] * f1) * f2;
 }
 
 // The piece products of one 16-deep step in issue order, smallest terms first: (piece of A, piece of B).
@@ -69,11 +118,17 @@ template <> struct Prods<3> {
     static constexpr int A[N] = {2, 0, 1, 1, 0, 0}, B[N] = {0, 2, 1, 0, 1, 0};
 };
 // acc += sum over the piece products of a (NP fragments) and b (NP fragments)
-template <int NP>
-__device__ __forceinline__ void mfma_pieces(f32x16& acc, const bf16x8 (&fa)[NP], const bf16x8 (&fb)[NP]) {
+template <int AR>
+__device__ __forceinline__ void mfma_pieces(f32x16& acc, const bf16x8 (&fa)[Ar<AR>::NP], const bf16x8 (&fb)[Ar<AR>::NP]) {
+    constexpr int NP = Ar<AR>::NP;
 #pragma unroll
-    for (int t = 0; t < Prods<NP>::N; ++t)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[Prods<NP>::A[t]], fb[Prods<NP>::B[t]], acc, 0, 0, 0);
+    for (int t = 0; t < Prods<NP>::N; ++t) {
+        if constexpr (Ar<AR>::F16)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[Prods<NP>::A[t]]),
+                                                         __builtin_bit_cast(f16x8, fb[Prods<NP>::B[t]]), acc, 0, 0, 0);
+        else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[Prods<NP>::A[t]], fb[Prods<NP>::B[t]], acc, 0, 0, 0);
+    }
 }
 
 template <typename TL, int TRANS_W, int NP>
@@ -101,9 +156,11 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane_at_tile, int P, in
     return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int NP, typename TL, int TRANS_W, int PRO, int EPI>
-__global__ __launch_bounds__(TL::NTH, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192 && NP == 2) ? 3 : 2))
+template <int AR, typename TL, int TRANS_W, int PRO, int EPI>
+__global__ __launch_bounds__(TL::NTH, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192 && AR == 2) ? 3 : 2))
 void pw_gemm_b3_kernel(PwArgs a) {
+    static_assert(AR == 2 || AR == 3, "fp32 weights split on the fly: the bf16 arithmetics only (h3 needs the weight's range)");
+    constexpr int NP = Ar<AR>::NP;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, NTH = TL::NTH;
     using L = B3<TL, TRANS_W, NP>;
     constexpr int PB = L::PB, PA = L::PA;
@@ -176,7 +233,7 @@ void pw_gemm_b3_kernel(PwArgs a) {
 #pragma unroll
         for (int j = 0; j < A_L; ++j) {
             bf16x4 q[NP];
-            split_x4<NP>(ra[j], q);
+            split_x4<AR>(ra[j], q, 1.f);
             if constexpr (TRANS_W == 0) {
                 const int r = tid / AT + (NTH / AT) * j, c = (tid % AT) * 4;
 #pragma unroll
@@ -193,7 +250,7 @@ void pw_gemm_b3_kernel(PwArgs a) {
             float4 v = rb[j];
             if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
             bf16x4 q[NP];
-            split_x4<NP>(v, q);
+            split_x4<AR>(v, q, 1.f);
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(Bp + (p * XK + i) * PB + k) = q[p];
         }
@@ -228,7 +285,7 @@ void pw_gemm_b3_kernel(PwArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) mfma_pieces<NP>(acc[i][j], af[i], bfr[j]);      // small terms first
+                for (int j = 0; j < NTL; ++j) mfma_pieces<AR>(acc[i][j], af[i], bfr[j]);      // small terms first
         }
     };
 
@@ -257,8 +314,9 @@ void pw_gemm_b3_kernel(PwArgs a) {
 // fp32 slabs summed in fixed order by slab_reduce_kernel.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WNT = 512;
-template <int NP, int PRO>
+template <int AR, int PRO>
 __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
+    constexpr int NP = Ar<AR>::NP;
     constexpr int PLANE = BM * XPA, STAGE = NP * PLANE;       // bf16 elements: one piece plane, all pieces of one operand
     __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * STAGE];          // [stage][piece][BM][XPA]   (NP = 3: 2 x 60 KiB)
     __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * STAGE];
@@ -284,6 +342,16 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
         p_mean = a.pro_ms[2 * m];
         p_rstd = a.pro_ms[2 * m + 1];
         p_alpha = a.pro_alpha[0];
+    }
+    // h3: per-utterance power-of-two scales of the two operands from their tracked maxima (a slab covers one utterance)
+    int eg = 0, ex = 0;
+    float sg = 1.f, sx = 1.f;
+    if constexpr (Ar<AR>::F16) {
+        eg = h3_exp(__uint_as_float(a.g_amax[m]));
+        const float xm = __uint_as_float(a.x_amax[m]);
+        ex = h3_exp(PRO == PRO_PRELU_NORM ? h3_pro_bound(xm, p_alpha, p_mean, p_rstd, a.pro_gbmax) : xm);
+        sg = h3_pow2(eg);
+        sx = h3_pow2(ex);
     }
     // staging map: 8 threads per row (32 frames = 8 float4), 64 rows per pass, 2 passes for 128 rows.  Rows past R / Cn
     // fall off the end of the utterance's matrix and read 0; frames past the chunk end are pushed out of range.
@@ -311,9 +379,9 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
             qb[j] = buf_ld4(rsX, (int)((unsigned)(((c0 + row) * a.Kp + k) * 4) + oob), 0);
         }
     };
-    auto write_one = [&](__bf16* P, int row, const float4& v) {
+    auto write_one = [&](__bf16* P, int row, const float4& v, float sc) {
         bf16x4 q[NP];
-        split_x4<NP>(v, q);
+        split_x4<AR>(v, q, sc);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(P + p * PLANE + row * XPA + kq) = q[p];
     };
@@ -321,11 +389,11 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (tid >> 3) + 64 * j;
-            write_one(Ap + stage * STAGE, row, qa[j]);
+            write_one(Ap + stage * STAGE, row, qa[j], sg);
             float4 x = qb[j];
             // (frames past the chunk end are frames >= Kp >= K: the prologue zeroes them like every frame >= K)
             if constexpr (PRO == PRO_PRELU_NORM) x = pro_apply(x, kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
-            write_one(Bp + stage * STAGE, row, x);
+            write_one(Bp + stage * STAGE, row, x, sx);
         }
     };
 
@@ -350,7 +418,7 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
                 bfr[p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + (wn * 32 + l31) * XPA + ks * 16 + lhi * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) mfma_pieces<NP>(acc[i], af[i], bfr);
+            for (int i = 0; i < 2; ++i) mfma_pieces<AR>(acc[i], af[i], bfr);
         }
     };
     // Register ring of PF k-tiles: at the top of iteration kt, LDS stage kt % 2 holds tile kt, ring slots (kt + 1 .. kt + PF - 1)
@@ -379,6 +447,7 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
             }
         }
     }
+    if constexpr (Ar<AR>::F16) h3_unscale<2>(acc, eg, ex);
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -429,9 +498,10 @@ __device__ unsigned long long ctn_dbg_tl[8192 * 12];
 #define CTN_TL_STAMP(i) do { } while (0)
 #endif
 
-template <int NP, typename TL, int PRO, int EPI>
-__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? (NP == 2 ? 4 : 3) : 2)
+template <int AR, typename TL, int PRO, int EPI>
+__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? (Ar<AR>::NP == 2 ? 4 : 3) : 2)
 void pw_gemm_b3p_kernel(PwArgs a) {
+    constexpr int NP = Ar<AR>::NP;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, NTH = TL::NTH;
     static_assert(TL::WGN == 1, "each wave owns its rows: 4 x 1 wave grid");
     using L = B3P<TL, NP>;
@@ -472,6 +542,15 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     const int nk = (a.Cn + XK - 1) / XK, Cnp = nk * XK;
 #endif
     const int Rp = (a.R + 31) / 32 * 32;
+    // h3: max |W| sits behind the weight's pieces (ctn_split_h3_batch), the activation's scale comes from its tracked maximum
+    int ew = 0, ex = 0;
+    float sx = 1.f;
+    if constexpr (Ar<AR>::F16) {
+        ew = h3_exp(__uint_as_float(*reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.W) + (size_t)Rp * Cnp * (2 * NP))));
+        const float xm = __uint_as_float(a.x_amax[m]);
+        ex = h3_exp(PRO == PRO_PRELU_NORM ? h3_pro_bound(xm, p_alpha, p_mean, p_rstd, a.pro_gbmax) : xm);
+        sx = h3_pow2(ex);
+    }
     // weight fragments: rows past Rp fall off the end of the planes and read 0 (rows R .. Rp-1 are stored as zeros)
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(a.W, (unsigned)Rp * (unsigned)Cnp * (2u * NP));
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xm, (unsigned)a.Cn * (unsigned)a.Kp * 4u);
@@ -525,7 +604,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
             q[0] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
             for (int p = 1; p < NP; ++p) q[p] = q[0];
 #else
-            split_x4<NP>(v, q);
+            split_x4<AR>(v, q, sx);
 #endif
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(S + (p * XK + i) * PB + k) = q[p];
@@ -564,7 +643,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
                         acc[i][j][p] += x.x * y.x; acc[i][j][p + 4] += x.y * y.y; acc[i][j][p + 8] += x.z * y.z; acc[i][j][p + 12] += x.w * y.w;
                     }
 #else
-                    mfma_pieces<NP>(acc[i][j], fa[i][ks], bfr[j]);
+                    mfma_pieces<AR>(acc[i][j], fa[i][ks], bfr[j]);
 #endif
                 }
         }
@@ -597,6 +676,10 @@ void pw_gemm_b3p_kernel(PwArgs a) {
 #ifdef CTN_EXP_B3_NOEPI
     if (a.K < 0) a.Out[tid] = acc[0][0][0] + acc[MT - 1][NTL - 1][15];      // never taken: keeps the accumulators live
 #else
+    if constexpr (Ar<AR>::F16) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) h3_unscale<NTL>(acc[i], ew, ex);
+    }
     gemm_epilogue<TL, EPI>(a, acc, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
 #endif
     CTN_TL_STAMP(3);
@@ -610,59 +693,110 @@ struct SplitArgs {
     __bf16* dst[SPLIT_MAX];
     int R, Cn, sr, sk, nkt;        // nkt = Cnp / 16
 };
-template <int NP>
+template <int AR>
 __global__ __launch_bounds__(256) void split_b3_kernel(SplitArgs a) {
+    constexpr int NP = Ar<AR>::NP;
     const float* __restrict__ W = a.src[blockIdx.z];
     __bf16* __restrict__ D = a.dst[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int kt = blockIdx.x * 4 + (threadIdx.x >> 6), rt = blockIdx.y;
     if (kt >= a.nkt) return;
+    float sc = 1.f;
+    if constexpr (Ar<AR>::F16) {        // h3: max |W| was put behind the pieces by absmax_batch_kernel; the GEMMs read it there too
+        const size_t pieces = (size_t)gridDim.y * 32 * (size_t)a.nkt * 16 * (2 * NP);
+        sc = h3_pow2(h3_exp(__uint_as_float(*reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(D) + pieces))));
+    }
     const int r = rt * 32 + (lane & 31), k0 = kt * 16 + (lane >> 5) * 8;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (r < a.R && k0 + e < a.Cn) ? W[(size_t)r * a.sr + (size_t)(k0 + e) * a.sk] : 0.f;
     bf16x4 q0[NP], q1[NP];
-    split_x4<NP>(make_float4(v[0], v[1], v[2], v[3]), q0);
-    split_x4<NP>(make_float4(v[4], v[5], v[6], v[7]), q1);
+    split_x4<AR>(make_float4(v[0], v[1], v[2], v[3]), q0, sc);
+    split_x4<AR>(make_float4(v[4], v[5], v[6], v[7]), q1, sc);
     __bf16* const blk = D + ((size_t)(rt * a.nkt + kt) * NP) * 512 + lane * 8;     // 512 bf16 = 1 KiB per block
 #pragma unroll
     for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8*>(blk + p * 512) = __builtin_shufflevector(q0[p], q1[p], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int NP, typename TL>
-void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
-    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
-    else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-    else if (residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (relu) hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_gemm_b3p_kernel<NP, TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+// ---- range tracking for the h3 arithmetic -----------------------------------------------------------------------------
+// dst[z][0] = bit pattern of max |src[z][0 .. n)| : one workgroup per (small) array -- weights, gamma / beta vectors.
+struct AbsmaxArgs {
+    const float* src[SPLIT_MAX];
+    unsigned* dst[SPLIT_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void absmax_batch_kernel(AbsmaxArgs a) {
+    __shared__ unsigned sc[4];
+    const float* __restrict__ S = a.src[blockIdx.x];
+    unsigned b = 0u;
+    const int n4 = a.n & ~3;
+    for (int i = threadIdx.x * 4; i < n4; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(S + i);
+        const unsigned t0 = __float_as_uint(fabsf(v.x)), t1 = __float_as_uint(fabsf(v.y));
+        const unsigned t2 = __float_as_uint(fabsf(v.z)), t3 = __float_as_uint(fabsf(v.w));
+        const unsigned u = (t0 > t1 ? t0 : t1), w = (t2 > t3 ? t2 : t3);
+        b = b > u ? b : u;
+        b = b > w ? b : w;
+    }
+    for (int i = n4 + threadIdx.x; i < a.n; i += 256) { const unsigned t = __float_as_uint(fabsf(S[i])); b = b > t ? b : t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned r = sc[0];
+        for (int w = 1; w < 4; ++w) r = r > sc[w] ? r : sc[w];
+        a.dst[blockIdx.x][0] = r;
+    }
+}
+// amax[m] = max(amax[m], max |x[m][0 .. n)|) : activations entering a stack (the caller zeroes amax); n % 4 == 0, 16-byte rows
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ amax) {
+    __shared__ double red[4];
+    const int m = blockIdx.y;
+    const float* __restrict__ X = x + (size_t)m * n;
+    float v = 0.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+        const float4 q = *reinterpret_cast<const float4*>(X + i);
+        v = fmaxf(fmaxf(v, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+        // (fmaxf drops NaNs; a NaN input still poisons the GEMM result through the operand itself)
+    }
+    block_amax_atomic<256>(v, red, amax + m);
 }
 
-template <int NP, typename TL>
+template <int AR, typename TL>
+void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+    const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+}
+
+template <int AR, typename TL>
 void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
-        if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else if (pro) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-        else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-        else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+        if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else if (pro) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+        else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+        else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
     } else if (pro) {
-        if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    } else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
-    else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
-    else if (relu) hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_gemm_b3_kernel<NP, TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
+        if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    } else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
+    else if (relu) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
 }
 
 }  // namespace
 
-// ---- host side, used by the entry points of ctn_gemm.hip (np = pieces per operand: 3 = b6, 2 = b3) ---------------------------
+// ---- host side, used by the entry points of ctn_gemm.hip (ar = arithmetic id of the kernels: 3 = b6, 2 = b3, 4 = h3) -------------
 static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step (b3) 11.56 / 11.20 / 11.50 ms
 static int g_ctn_b3_wgrad_blocks = 256;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
@@ -680,37 +814,56 @@ static int ctn_b3_pick_tile(const PwArgs& a, int trans_w, bool pro, bool residua
     return g_ctn_b3_tile;
 }
 
-template <int NP>
+template <int AR>
 static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     if (trans_w == 2) {             // a.W = fragment-ordered pieces (ctn_split_b3_batch)
         switch (tile) {
-            case 1: launch_b3p_tile<NP, Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
-            case 2: launch_b3p_tile<NP, Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
-            default: launch_b3p_tile<NP, Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            case 1: launch_b3p_tile<AR, Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            case 2: launch_b3p_tile<AR, Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            default: launch_b3p_tile<AR, Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
         }
         return;
     }
-    switch (tile) {
-        case 1: launch_b3_tile<NP, T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        case 2: launch_b3_tile<NP, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-        default: launch_b3_tile<NP, T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+    if constexpr (AR != 4) {        // fp32 weights split on the fly: the bf16 arithmetics
+        switch (tile) {
+            case 1: launch_b3_tile<AR, T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+            case 2: launch_b3_tile<AR, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+            default: launch_b3_tile<AR, T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+        }
     }
 }
 
-static void ctn_b3_launch_fwd(int np, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+static void ctn_b3_launch_fwd(int ar, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
     static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
     const int tile = ctn_b3_pick_tile(a, trans_w, pro, residual, stats, gln_bwd);
     a.tiles_r = ctn_cdiv(a.R, d[tile][0]);
     a.tiles_c = ctn_cdiv(a.Kp, d[tile][1]);
-    if (np == 3) ctn_b3_launch_fwd_np<3>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
+    if (ar == 4) ctn_b3_launch_fwd_np<4>(tile, a, 2, pro, residual, stats, relu, gln_bwd, st);       // (pre-split weights only)
+    else if (ar == 3) ctn_b3_launch_fwd_np<3>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
     else ctn_b3_launch_fwd_np<2>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
 }
 
-static size_t ctn_b3_planes_bytes(int np, int R, int Cn) {
-    return (size_t)((R + 31) / 32 * 32) * (size_t)((Cn + XK - 1) / XK * XK) * 2 * (size_t)np;
+// bytes of one pre-split weight operand; h3 appends 16 bytes: the bit pattern of max |W| (the scale is derived from it)
+static size_t ctn_b3_pieces_bytes(int ar, int R, int Cn) {
+    return (size_t)((R + 31) / 32 * 32) * (size_t)((Cn + XK - 1) / XK * XK) * 2 * (size_t)(ar == 4 ? 2 : ar);
+}
+static size_t ctn_b3_planes_bytes(int ar, int R, int Cn) { return ctn_b3_pieces_bytes(ar, R, Cn) + (ar == 4 ? 16 : 0); }
+
+static void ctn_b3_launch_absmax(const void* const* src, void* const* dst, size_t dst_offset, int n, int len, hipStream_t st) {
+    for (int o = 0; o < n; o += SPLIT_MAX) {
+        AbsmaxArgs aa{};
+        const int cnt = n - o < SPLIT_MAX ? n - o : SPLIT_MAX;
+        for (int i = 0; i < cnt; ++i) {
+            aa.src[i] = (const float*)src[o + i];
+            aa.dst[i] = (unsigned*)((char*)dst[o + i] + dst_offset);
+        }
+        aa.n = len;
+        hipLaunchKernelGGL(absmax_batch_kernel, dim3(cnt), dim3(256), 0, st, aa);
+    }
 }
 
-static void ctn_b3_launch_split(int np, const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, hipStream_t st) {
+static void ctn_b3_launch_split(int ar, const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, hipStream_t st) {
+    if (ar == 4) ctn_b3_launch_absmax(src, dst, ctn_b3_pieces_bytes(4, R, Cn), n, R * Cn, st);
     for (int o = 0; o < n; o += SPLIT_MAX) {
         SplitArgs sa{};
         const int cnt = n - o < SPLIT_MAX ? n - o : SPLIT_MAX;
@@ -722,7 +875,8 @@ static void ctn_b3_launch_split(int np, const void* const* src, void* const* dst
         sa.sr = k_major ? 1 : Cn; sa.sk = k_major ? R : 1;
         sa.nkt = (Cn + XK - 1) / XK * 2;
         const dim3 grid(ctn_cdiv(sa.nkt, 4), (R + 31) / 32, cnt);
-        if (np == 3) hipLaunchKernelGGL(split_b3_kernel<3>, grid, dim3(256), 0, st, sa);
+        if (ar == 4) hipLaunchKernelGGL(split_b3_kernel<4>, grid, dim3(256), 0, st, sa);
+        else if (ar == 3) hipLaunchKernelGGL(split_b3_kernel<3>, grid, dim3(256), 0, st, sa);
         else hipLaunchKernelGGL(split_b3_kernel<2>, grid, dim3(256), 0, st, sa);
     }
 }
@@ -738,20 +892,21 @@ static void ctn_b3_wgrad_plan(int M, int R, int Cn, int Kp, int* chunk, int* chu
     *chunks_per_m = ctn_cdiv(Kp, c);
 }
 
-template <int NP>
+template <int AR>
 static void ctn_b3_launch_wgrad_np(const WgArgs& a, bool pro, dim3 grid, hipStream_t st) {
     const dim3 block(WNT);
-    if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_PRELU_NORM>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<NP, PRO_NONE>), grid, block, 0, st, a);
+    if (pro) hipLaunchKernelGGL((pw_wgrad_b3_kernel<AR, PRO_PRELU_NORM>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pw_wgrad_b3_kernel<AR, PRO_NONE>), grid, block, 0, st, a);
 }
 
 // a.chunk / a.chunks_per_m / a.slab already set by the caller from ctn_b3_wgrad_plan; returns the number of slabs
-static int ctn_b3_launch_wgrad(int np, WgArgs& a, bool pro, hipStream_t st) {
+static int ctn_b3_launch_wgrad(int ar, WgArgs& a, bool pro, hipStream_t st) {
     a.tiles_r = ctn_cdiv(a.R, BM);
     a.tiles_c = ctn_cdiv(a.Cn, BN);
     const int nsplit = a.M * a.chunks_per_m;
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit));
-    if (np == 3) ctn_b3_launch_wgrad_np<3>(a, pro, grid, st);
+    if (ar == 4) ctn_b3_launch_wgrad_np<4>(a, pro, grid, st);
+    else if (ar == 3) ctn_b3_launch_wgrad_np<3>(a, pro, grid, st);
     else ctn_b3_launch_wgrad_np<2>(a, pro, grid, st);
     return nsplit;
 }

@@ -60,6 +60,10 @@ struct PwArgs {
     const float* epi_alpha; double* epi_part;      // EPI_PRELU_STATS: [M, tiles_r*tiles_c, 2]
     const float* bwd_y; const float* bwd_gamma; const float* bwd_alpha;
     const float* bwd_ms; double* bwd_part;         // EPI_GLN_BWD
+    // h3 arithmetic (ctn_gemm_b3.h): range information of the operands, all optional elsewhere
+    const unsigned* x_amax;   // [M] bit pattern of max |X[m]| as stored (before the prologue): scale of the B operand
+    const float* pro_gbmax;   // {max |gamma|, max |beta|} of the prologue's norm
+    unsigned* out_amax;       // EPI_RESIDUAL: [M] atomic max of |Out[m]| (caller zeroes it), for the GEMMs that read Out next
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -133,7 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     constexpr int C4 = WN / 4;              // lanes per staged row
     constexpr int RPP = 64 / C4;            // rows per pass
     float* const stage = smem + wave * 32 * LST;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, amax = 0.f;
     const size_t mbase = (size_t)m * a.R * a.Kp;
     const unsigned mat_bytes = (unsigned)a.R * (unsigned)a.Kp * 4u;
     const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, mat_bytes);
@@ -167,6 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                 if constexpr (EPI == EPI_RESIDUAL) {
                     const float4 q = buf_ld4(rsAux, vo0, so);
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 }
                 if constexpr (EPI == EPI_RELU) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -195,6 +200,10 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (EPI == EPI_RESIDUAL) {
+        // (rows >= R / columns >= Kp never reach `amax`: the loop skips them or they are exact zeros)
+        if (a.out_amax != nullptr) block_amax_atomic<TL::NTH>(amax, red, a.out_amax + m);
+    }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
         const double d1 = block_sum<double, TL::NTH>((double)s1, red);
         const double d2 = block_sum<double, TL::NTH>((double)s2, red);
@@ -220,6 +229,8 @@ struct WgArgs {
     int M, R, Cn, K, Kp;
     int tiles_r, tiles_c, chunk, chunks_per_m;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
+    // h3 arithmetic: [M] bit patterns of max |dOut[m]| / max |X[m]| (as stored), {max |gamma|, max |beta|} of the prologue
+    const unsigned* g_amax; const unsigned* x_amax; const float* pro_gbmax;
 };
 
 

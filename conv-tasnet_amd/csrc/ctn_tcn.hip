@@ -37,6 +37,7 @@ struct DwFwdArgs {
     const double* pro_part; int pro_nparts;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; float* pro_ms_out;
     const float* epi_alpha; double* epi_part;   // [M, H, 2]
+    unsigned* amax_out;                         // EPI: [M] atomic max of |Z[m]| (h3 arithmetic of the GEMM that reads Z), optional
 };
 
 template <bool PRO, bool EPI, int FWD_BUF, bool VEC4, int PT>      // PT: compile-time kernel size (3) or 0 = a.P at run time
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
     float e_alpha = 0.f;
     if constexpr (EPI) e_alpha = a.epi_alpha[0];
     const int halo = (P_ - 1) * a.dil;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, amax = 0.f;
 
     for (int k0 = 0; k0 < a.Kp; k0 += a.seg) {
         const int kend = min(k0 + a.seg, a.Kp);
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
                     const float p2 = prelu_f(acc.z, e_alpha), p3 = prelu_f(acc.w, e_alpha);
                     s1 += (p0 + p1) + (p2 + p3);
                     s2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
                 }
                 if (live) *reinterpret_cast<float4*>(z + k) = acc;
             }
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
                 const float p = prelu_f(acc, e_alpha);
                 s1 += p;
                 s2 += p * p;
+                amax = fmaxf(amax, fabsf(acc));
             }
             if (live) z[k] = acc;
         }
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             dst[0] = d1;
             dst[1] = d2;
         }
+        if (a.amax_out != nullptr) block_amax_atomic<NT>(amax, red, a.amax_out + m);      // (dead waves hold 0)
     }
 }
 
@@ -419,7 +423,8 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
                                                            float* __restrict__ dY, int M, int H, int K, int Kp,
                                                            const float* __restrict__ gamma, const float* __restrict__ alpha_p,
                                                            const float* __restrict__ ms, const double* __restrict__ sums_part,
-                                                           int nparts, float* __restrict__ dalpha_part) {
+                                                           int nparts, float* __restrict__ dalpha_part,
+                                                           unsigned* __restrict__ amax_out) {
     __shared__ double red[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hb = (H + ROWS - 1) / ROWS;
@@ -432,14 +437,14 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
     }
     S1 = block_sum<double, NT>(S1, red);
     S2 = block_sum<double, NT>(S2, red);
-    if (c >= H) return;
+    const bool live = c < H;
     const double n = (double)H * (double)K;
     const float c1 = (float)(S1 / n), c2 = (float)(S2 / n);
-    const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha_p[0], g = gamma[c];
+    const float mean = ms[2 * m], rstd = ms[2 * m + 1], al = alpha_p[0], g = live ? gamma[c] : 0.f;
     const float ar = al * rstd, mr = mean * rstd, rg = rstd * g, rc1 = rstd * c1, rc2 = rstd * c2;
     const size_t row = ((size_t)m * H + c) * Kp;
-    float dal = 0.f;
-    for (int k = lane * 4; k < Kp; k += 256) {
+    float dal = 0.f, amax = 0.f;
+    for (int k = lane * 4; live && k < Kp; k += 256) {
         const float4 dn = ld4(dN + row + k);
         const float4 y = ld4(Y + row + k);
         const float dv[4] = {dn.x, dn.y, dn.z, dn.w};
@@ -453,10 +458,12 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
             if (valid && yv[e] < 0.f) dal += da * yv[e];
             o[e] = valid ? (yv[e] >= 0.f ? da : al * da) : 0.f;
         }
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         *reinterpret_cast<float4*>(dY + row + k) = make_float4(o[0], o[1], o[2], o[3]);
     }
     dal = wave_sum(dal);
-    if (lane == 0) dalpha_part[(size_t)m * H + c] = dal;
+    if (live && lane == 0) dalpha_part[(size_t)m * H + c] = dal;
+    if (amax_out != nullptr) block_amax_atomic<NT>(amax, red, amax_out + m);
 }
 
 // ---------------------------------------------------------------------------
@@ -1063,8 +1070,10 @@ extern "C" {
 
 int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
                const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
-               const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, void* stream) {
+               const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, unsigned* amax_out,
+               void* stream) {
     CTN_REQUIRE(Y && Z && D, "ctn_dw_fwd: null pointer");
+    CTN_REQUIRE(!amax_out || epi_part, "ctn_dw_fwd: amax_out comes with the statistics epilogue");
     CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_dw_fwd: bad sizes");
     CTN_REQUIRE(P >= 1 && P <= MAXP && dilation >= 1, "ctn_dw_fwd: kernel size %d unsupported (max %d)", P, MAXP);
     CTN_REQUIRE(aligned16(Y) && aligned16(Z), "ctn_dw_fwd: pointers must be 16-byte aligned");
@@ -1080,6 +1089,7 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
     a.padl = causal ? halo : halo / 2; a.seg = seg;
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
+    a.amax_out = amax_out;
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = (a.dil % 4 == 0) && (a.padl % 4 == 0);
@@ -1182,12 +1192,12 @@ int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* strea
 
 int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
                       const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
-                      float* dalpha_part, void* stream) {
+                      float* dalpha_part, unsigned* amax_out, void* stream) {
     CTN_REQUIRE(dN && Y && dY && gamma && alpha && ms && sums_part && dalpha_part && nparts > 0, "ctn_gln_prelu_bwd: null pointer");
     CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_gln_prelu_bwd: bad sizes");
     CTN_REQUIRE(aligned16(dN) && aligned16(Y) && aligned16(dY), "ctn_gln_prelu_bwd: alignment");
     hipLaunchKernelGGL(gln_prelu_bwd_kernel, dim3((unsigned)(M * ctn_cdiv(H, ROWS))), dim3(NT), 0, (hipStream_t)stream,
-                       dN, Y, dY, M, H, K, Kp, gamma, alpha, ms, sums_part, nparts, dalpha_part);
+                       dN, Y, dY, M, H, K, Kp, gamma, alpha, ms, sums_part, nparts, dalpha_part, amax_out);
     CTN_CHECK_LAUNCH("ctn_gln_prelu_bwd");
     return CTN_OK;
 }

@@ -14,6 +14,7 @@ autograd node:
   Backend  : mask 1x1 -> relu|softmax -> mask*w -> basis -> OLA   (src/conv_tasnet.py:191,206-215,131-146)
   SiSnrPit : PIT SI-SNR loss                                      (src/pit_criterion.py:12-77)
 """
+import ctypes
 import itertools
 import os
 
@@ -25,12 +26,13 @@ F32 = torch.float32
 F64 = torch.float64
 BF16 = torch.bfloat16
 
-_ARITH_NAMES = ("fp32", "b3", "b6")        # ids of ctn_gemm_arith / ctn_tune("arith", id)
+_ARITH_NAMES = ("fp32", "b3", "b6", "h3")        # ids of ctn_gemm_arith / ctn_tune("arith", id)
 
 
 def gemm_arith():
-    """'b6' (default: three bf16 pieces per fp32 operand, six bf16 MFMAs, fp32 accumulation -- fp32-faithful products),
-    'fp32' (fp32-MFMA kernels, bit-exact fp32 FMA chains) or 'b3' (opt-in: two pieces, three MFMAs, ~16-bit products)."""
+    """'h3' (default: the composite stacks multiply two fp16 pieces per fp32 operand under tracked power-of-two scales, three f16
+    MFMAs, fp32 accumulation -- fp32-faithful products; every other GEMM as b6), 'b6' (three bf16 pieces per operand, six bf16
+    MFMAs), 'fp32' (fp32-MFMA kernels, bit-exact fp32 FMA chains) or 'b3' (opt-in: two bf16 pieces, three MFMAs, ~16-bit products)."""
     return _ARITH_NAMES[lib.ctn_gemm_arith()]
 
 
@@ -152,6 +154,78 @@ def _b3_pieces(W, R, Cn, k_major):
     dst_t = (ctypes.c_void_p * 1)(dst.data_ptr())
     lib.call("ctn_split_b3_batch", src_t, dst_t, 1, R, Cn, int(k_major), _stream())
     return dst
+
+
+# ---- h3 arithmetic (include/ctn_hip.h, "h3" section): the same GEMM forms on two fp16 pieces per operand, with the operands'
+# per-utterance maxima as explicit inputs.  The composite stacks drive these entry points from C++; the wrappers are the
+# unit-tested surface.
+def h3_pieces(W, R, Cn, k_major):
+    """fp16 piece fragments (+ the weight's maximum) of one GEMM weight operand [R, Cn]; W stored [Cn, R] when k_major."""
+    _chk(W)
+    dst = torch.empty(lib.ctn_split_h3_bytes(R, Cn), dtype=torch.uint8, device=W.device)
+    lib.call("ctn_split_h3_batch", (ctypes.c_void_p * 1)(W.data_ptr()), (ctypes.c_void_p * 1)(dst.data_ptr()), 1, R, Cn,
+             int(k_major), _stream())
+    return dst
+
+
+def absmax_rows(x, out=None):
+    """int32 [M]: bit patterns of max |x[m]| (merged into `out` when given)."""
+    _chk(x)
+    M = x.shape[0]
+    if out is None:
+        out = torch.zeros((M,), dtype=torch.int32, device=x.device)
+    lib.call("ctn_absmax_rows", _p(x), M, x[0].numel(), _p(out), _stream())
+    return out
+
+
+def absmax_of(*vectors):
+    """float32 [len(vectors)]: max |v| of each (equally long) parameter vector -- pro_gbmax = absmax_of(gamma, beta)."""
+    _chk(*vectors)
+    out = torch.empty((len(vectors),), dtype=F32, device=vectors[0].device)
+    n = len(vectors)
+    lib.call("ctn_absmax_batch", (ctypes.c_void_p * n)(*[v.data_ptr() for v in vectors]),
+             (ctypes.c_void_p * n)(*[out.data_ptr() + 4 * i for i in range(n)]), n, vectors[0].numel(), _stream())
+    return out
+
+
+def pw_gemm_h3(Wp, X, R, Cn, K, x_amax, pro=None, gbmax=None, residual=None, epi_alpha=None, ms_out=None, out_amax=None):
+    """ctn_pw_gemm_h3: Out = W . f(X) on h3 pieces Wp (h3_pieces).  Returns (Out, epi_part|None)."""
+    M, _, Kp = X.shape
+    out = torch.empty((M, R, Kp), dtype=F32, device=X.device)
+    epi_part = None
+    if epi_alpha is not None:
+        epi_part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=X.device)
+    pp, npart, pg, pb, pa = (None, 0, None, None, None) if pro is None else (pro[0], pro[0].shape[1], pro[1], pro[2], pro[3])
+    _chk(X, pg, pb, pa, residual, epi_alpha, ms_out, gbmax)
+    _chk_aux(pp, x_amax, out_amax)
+    lib.call("ctn_pw_gemm_h3", _p(Wp), _p(X), _p(out), M, R, Cn, K, Kp, _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out),
+             _p(residual), _p(epi_alpha), _p(epi_part), _p(x_amax), _p(gbmax), _p(out_amax), _stream())
+    return out, epi_part
+
+
+def pw_dgrad_gln_h3(Wp, dOut, R, Cn, K, y, gamma, alpha, ms, g_amax):
+    M, _, Kp = dOut.shape
+    dn = torch.empty((M, R, Kp), dtype=F32, device=dOut.device)
+    part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 2), dtype=F64, device=dOut.device)
+    _chk(dOut, y, gamma, alpha, ms)
+    _chk_aux(g_amax)
+    lib.call("ctn_pw_dgrad_gln_h3", _p(Wp), _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha), _p(ms), _p(part),
+             _p(g_amax), _stream())
+    return dn, part
+
+
+def pw_wgrad_h3(dOut, X, R, Cn, K, g_amax, x_amax, pro=None, gbmax=None):
+    """ctn_pw_wgrad_h3: dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2])."""
+    M, _, Kp = X.shape
+    dW = torch.empty((R, Cn), dtype=F32, device=X.device)
+    nbytes = lib.ctn_pw_wgrad_h3_workspace(M, R, Cn, Kp)
+    ws = _workspace(nbytes, X.device, "wgrad_h3")
+    pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
+    _chk(dOut, X, pg, pb, pa, pms, gbmax)
+    _chk_aux(g_amax, x_amax)
+    lib.call("ctn_pw_wgrad_h3", _p(dOut), _p(X), _p(dW), M, R, Cn, K, Kp, _p(pg), _p(pb), _p(pa), _p(pms), _p(g_amax), _p(x_amax),
+             _p(gbmax), _p(ws), nbytes, _stream())
+    return dW
 
 
 def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
@@ -302,7 +376,7 @@ def dw_fwd(Y, D, K, dilation, causal, pro=None, epi_alpha=None, ms_out=None):
     _chk(Y, D, pg, pb, pa, epi_alpha, ms_out)
     _chk_aux(pp)
     lib.call("ctn_dw_fwd", _p(Y), _p(Z), _p(D), M, H, K, Kp, P, dilation, int(causal),
-             _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(epi_alpha), _p(epi_part), _stream())
+             _p(pp), npart, _p(pg), _p(pb), _p(pa), _p(ms_out), _p(epi_alpha), _p(epi_part), 0, _stream())
     return Z, epi_part
 
 
@@ -432,7 +506,7 @@ class GlnBlock(torch.autograd.Function):
             da1 = torch.empty((1,), dtype=F32, device=dev)
         # -- gLN1 + PReLU1 backward, in place on dn1
         da1p = torch.empty((M * H,), dtype=F32, device=dev)
-        lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), st)
+        lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), 0, st)
 
         # The fixed-order finishing reductions (one launch: depthwise-weight / gamma / beta / both alpha gradients) feed
         # only parameter gradients.  CTN_SIDE_FIN=1 issues them with the first layer's weight gradient on the second
@@ -511,10 +585,11 @@ def tcn_gln_infer(x0, K, dilations, causal, params):
     h1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
     d = torch.empty((M, H, Kp), dtype=F32, device=dev)
     ms = torch.empty((2, M, 2), dtype=F32, device=dev)
+    amax = torch.empty((nb, 2, M), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked operand maxima (zeroed by the call)
     nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp, nb)
     ws = _workspace(nbytes, dev, "tcn_fwd")
     dil = (ctypes.c_int * nb)(*dilations)
-    lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1), _p(d), _p(ms), 0,
+    lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1), _p(d), _p(ms), _p(amax), 0,
              M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
     return xs[(nb - 1) & 1]
 
@@ -538,13 +613,14 @@ class TcnGln(torch.autograd.Function):
         h1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
         ds = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
         ms = torch.empty((nb, 2, M, 2), dtype=F32, device=dev)
+        amax = torch.empty((nb, 2, M), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked maxima of every block's input / depthwise output
         nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp, nb)
         ws = _workspace(nbytes, dev, "tcn_fwd")
         dil = (ctypes.c_int * nb)(*dilations)
-        lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms), 1,
+        lib.call("ctn_tcn_gln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h1s), _p(ds), _p(ms), _p(amax), 1,
                  M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
         # our own buffers, written once and read once by backward: plain attributes (released as soon as they are consumed)
-        ctx.acts = (x0, xs, h1s, ds, ms)
+        ctx.acts = (x0, xs, h1s, ds, ms, amax)
         ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
         ctx.cfg = (K, dil, nb, causal, P)
         ctx.sinks = tuple(_sink(p) for p in params)
@@ -555,7 +631,7 @@ class TcnGln(torch.autograd.Function):
         if ctx.acts is None:
             raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
                            "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
-        x0, xs, h1s, ds, ms = ctx.acts
+        x0, xs, h1s, ds, ms, amax = ctx.acts
         params = ctx.saved_tensors
         K, dil, nb, causal, P = ctx.cfg
         dout = _c(dout)
@@ -589,7 +665,7 @@ class TcnGln(torch.autograd.Function):
             wsi = _workspace(nbi, dev, "tcn_bwd_bucket%d" % i) if unjoined else ws
             lib.call("ctn_tcn_gln_bwd", _ptr_table(params[lo * NPARAM:hi * NPARAM]), _ptr_table(gdst[lo * NPARAM:hi * NPARAM]),
                      (ctypes.c_int * (hi - lo))(*dil[lo:hi]), hi - lo, _p(x0 if lo == 0 else xs[lo - 1]), _p(xs[lo]), _p(h1s[lo]),
-                     _p(ds[lo]), _p(ms[lo]), _p(dout if hi == nb else dxs[hi]), _p(dxs[lo]), _p(dn1s[lo]), M, B, H, K, Kp, P,
+                     _p(ds[lo]), _p(ms[lo]), _p(amax[lo]), _p(dout if hi == nb else dxs[hi]), _p(dxs[lo]), _p(dn1s[lo]), M, B, H, K, Kp, P,
                      int(causal), _p(wsi), nbi, _stream(), 0 if side is None else side.cuda_stream, int(unjoined))
             if gb is not None:
                 with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):

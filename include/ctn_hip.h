@@ -88,13 +88,15 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE).  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
- *   2 = "b6" (default): every fp32 operand is split EXACTLY into three bf16 pieces (a = a0 + a1 + a2, round-to-nearest-even)
+ *   3 = "h3" (default): the GEMMs of the composite stacks (ctn_tcn_*) run on the ctn_*_h3 entry points below -- two fp16 pieces
+ *       per fp32 operand under a tracked power-of-two scale, three f16 MFMAs, fp32 accumulation; every other GEMM as b6;
+ *   2 = "b6": every fp32 operand is split EXACTLY into three bf16 pieces (a = a0 + a1 + a2, round-to-nearest-even)
  *       and a.b is formed from the six piece-products of weight >= 2^-17 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
  *       the dropped terms are <= 2^-23 |a.b| -- one fp32 rounding of the product.  Measured against fp64 the error of every
  *       GEMM form is that of the fp32 MFMA (3.4e-7 vs 4.0e-7 of sum |a||b|, profiles/r03_a_b6_check.txt);
  *   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains;
  *   1 = "b3" (opt-in, NOT reference precision): two pieces per operand, three products, ~16 significant bits per product.
- * Selected by CTN_GEMM_ARITH=b6|fp32|b3 at first use or ctn_tune("arith", 2|0|1) between steps; layers with fewer than 64
+ * Selected by CTN_GEMM_ARITH=h3|b6|fp32|b3 at first use or ctn_tune("arith", 3|2|0|1) between steps; layers with fewer than 64
  * output rows (and weight gradients with a side below 32) always use the fp32-MFMA kernels. */
 int ctn_gemm_arith(void);
 /* Split-bf16 arithmetics only: the weight operand pre-split once per step.  dst[i] receives the bf16 pieces of the GEMM operand
@@ -109,6 +111,43 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
                             const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
                             void* stream);
 
+/* ---- "h3" arithmetic: fp32-faithful products from TWO fp16 pieces per operand (three f16 MFMAs instead of b6's six) ------
+ * replaces the same fp32 nn.Conv1d(*, *, 1) layers (src/conv_tasnet.py:223,262) inside the composite stacks.
+ *   a s = a0 + a1 + r,  a0 = fp16_rne(a s), a1 = fp16_rne(a s - a0):  two 11-bit significands + the sign of a1 hold 23-24 bits,
+ *   |r| <= 2^-24 |a s|;   a.b ~= (a1.b0 + a0.b1 + a0.b0) / (s_a s_b)  on v_mfma_f32_32x32x16_f16, fp32 accumulation; dropped:
+ *   a1.b1 + r_a.b + a.r_b, <= 3 * 2^-24 |a.b| -- the size of the rounding an fp32 FMA chain commits per step (b6 drops 2 * 2^-24).
+ * fp16 has 5 exponent bits, so every operand is brought into range by an exact power-of-two scale s derived from a bound on
+ * its magnitude: the weight's own maximum (computed by ctn_split_h3_batch), and for activations the per-utterance maximum
+ * max |X[m]| TRACKED BY THE KERNEL THAT PRODUCED X -- `amax` arrays: [M] unsigned, the bit pattern of a non-negative float,
+ * merged with atomic max (exact, order-free: results stay bitwise reproducible); the caller zeroes them before the producer
+ * runs.  Producers: ctn_absmax_rows (any tensor), ctn_pw_gemm_h3 (residual epilogue, out_amax), ctn_dw_fwd and
+ * ctn_gln_prelu_bwd (amax_out).  With an operand prologue the scale comes from the bound
+ * max|gamma| * rstd * (max(1,|alpha|) * amax + |mean|) + max|beta|  (pro_gbmax = {max|gamma|, max|beta|}: ctn_absmax_batch).
+ * Scaled values stay below 2^14 (fp16 holds 65504).  Elements within 2^-17 of their utterance's maximum keep the full
+ * 2^-24 relative precision; smaller ones degrade gracefully (absolute error <= 2^-39 of the maximum).  Same tiles, statistics
+ * layouts (ctn_pw_stats_parts of the split arithmetics), epilogues and fixed-order reductions as the plain entry points.
+ * These entry points do not depend on ctn_tune("arith"); R >= 64 (weight gradient: both sides >= 32). */
+size_t ctn_split_h3_bytes(int R, int Cn);
+int ctn_split_h3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream);
+/* dst[i][0] = bit pattern of max |src[i][0 .. len)|  (HOST arrays of device pointers; dst[i]: 4 bytes) */
+int ctn_absmax_batch(const void* const* src, void* const* dst, int n, int len, void* stream);
+/* amax[m] = max(amax[m], bits of max |x[m][0 .. n)|),  x: [M, n] fp32, n % 4 == 0 */
+int ctn_absmax_rows(const float* x, int M, long long n, unsigned* amax, void* stream);
+/* ctn_pw_gemm(trans_w = 2) on h3 pieces.  x_amax [M]: maximum of X as stored; pro_gbmax with the prologue; out_amax [M]
+ * (optional, with residual): receives the maximum of Out. */
+int ctn_pw_gemm_h3(const void* Wp, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
+                   const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
+                   const float* pro_alpha, float* pro_ms_out, const float* residual, const float* epi_alpha, double* epi_part,
+                   const unsigned* x_amax, const float* pro_gbmax, unsigned* out_amax, void* stream);
+int ctn_pw_dgrad_gln_h3(const void* Wp, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                        const float* y, const float* gamma, const float* alpha, const float* ms, double* sums_part,
+                        const unsigned* g_amax, void* stream);
+int ctn_pw_wgrad_h3(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                    const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                    const unsigned* g_amax, const unsigned* x_amax, const float* pro_gbmax,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t ctn_pw_wgrad_h3_workspace(int M, int R, int Cn, int Kp);
+
 /* ---- depthwise dilated conv (+ fused PReLU / gLN) ---------------------------------------
  * replaces DepthwiseSeparableConv.net[0] (+Chomp1d), src/conv_tasnet.py:253-256,281-295, with the
  * PReLU (:224,:259) and GlobalLayerNorm (:225,:260,:338-361) on either side fused in. */
@@ -116,10 +155,12 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
 /* Z[m,h,k] = sum_j D[h,j] * n[m,h,k + j*dilation - pad_left],  zeros outside [0,K);
  *   pad_left = (P-1)*dilation/2 (non-causal "same") or (P-1)*dilation (causal, = pad + Chomp1d).
  *   pro_part != NULL: n = gLN(prelu(Y)) as in ctn_pw_gemm; else n = Y.
- *   epi_part != NULL: partials of prelu(Z, epi_alpha), layout [M, H, 2] fp64. */
+ *   epi_part != NULL: partials of prelu(Z, epi_alpha), layout [M, H, 2] fp64;
+ *   amax_out != NULL (with epi_part): amax_out[m] = max(amax_out[m], bits of max |Z[m]|) -- see the h3 section. */
 int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
                const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
-               const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, void* stream);
+               const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, unsigned* amax_out,
+               void* stream);
 
 /* Backward of the above.  fused = 1 walks  gLN2 <- PReLU2 <- depthwise <- (gLN1 output)  in one pass:
  *   in : dN2 (grad of gLN2's output), Dz (= Z of the forward), Y1 (= Y of the forward),
@@ -146,10 +187,11 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
 int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* stream);
 
 /* dY = rstd*(gamma*dN - S1/n - xhat*S2/n) * prelu'(Y);  dalpha_part [M*H] = per-row sum over Y<0 of (..)*Y.
- * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN. */
+ * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN.
+ * amax_out != NULL: amax_out[m] = max(amax_out[m], bits of max |dY[m]|) -- see the h3 section. */
 int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
                       const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
-                      float* dalpha_part, void* stream);
+                      float* dalpha_part, unsigned* amax_out, void* stream);
 
 /* First pass of the STAND-ALONE gLN(prelu(Y)) backward (GlobalLayerNorm used as a module of its own,
  * src/conv_tasnet.py:338-361; inside a TemporalBlock these sums come out of the GEMM / depthwise epilogues):
@@ -170,8 +212,10 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
  *   x0 [M,B,Kp]: input of block 0.  Forward writes, backward reads (all device, caller-owned):
  *     xs  [nblocks][M,B,Kp]  block outputs (xs[nblocks-1] is the stack's output),
  *     h1s [nblocks][M,H,Kp]  first 1x1 outputs,  ds [nblocks][M,H,Kp] depthwise outputs,
- *     ms  [nblocks][2][M][2] (mean, rstd) of the two gLNs.
- *     save = 0 (inference): xs needs 2 slots, h1s / ds / ms one slot each; the output is xs[(nblocks-1) & 1].
+ *     ms  [nblocks][2][M][2] (mean, rstd) of the two gLNs,
+ *     amax [nblocks][2][M] unsigned (h3 arithmetic; may be NULL otherwise): the tracked maxima of every block's input and of
+ *          its depthwise output (see the h3 section); written by the forward pass (which zeroes it first), read by backward.
+ *     save = 0 (inference): xs needs 2 slots, h1s / ds / ms one slot each (amax all nblocks); the output is xs[(nblocks-1) & 1].
  *   forward with side_stream != NULL and M >= 2: the batch runs as two half-batch chains on the two streams (utterances are
  *     independent; one half's HBM-bound phases overlap the other half's MFMA phases); same values bit for bit; on return `stream`
  *     is ordered after both.
@@ -185,12 +229,12 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
  *     are read on `stream`.  A stack may be run as several calls over consecutive block ranges (last blocks first).
  *   workspace: ctn_tcn_gln_{fwd,bwd}_workspace() bytes, 256-byte aligned. */
 int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
-                    float* xs, float* h1s, float* ds, float* ms, int save,
+                    float* xs, float* h1s, float* ds, float* ms, unsigned* amax, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 size_t ctn_tcn_gln_fwd_workspace(int M, int B, int H, int Kp, int nblocks);
 int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
-                    const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms,
+                    const float* x0, const float* xs, const float* h1s, const float* ds, const float* ms, const unsigned* amax,
                     const float* dout, float* dxs, float* dn1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags);

@@ -38,7 +38,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     # null pointers / bad sizes are rejected before any launch, so this is safe without a GPU
     rc = ctn.lib.ctn_pw_gemm(0, 0, 0, 1, 4, 4, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc == -1 and b"null" in ctn.lib.ctn_last_error()
-    rc = ctn.lib.ctn_dw_fwd(16, 16, 16, 1, 4, 8, 8, 99, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    rc = ctn.lib.ctn_dw_fwd(16, 16, 16, 1, 4, 8, 8, 99, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc == -1 and b"kernel size" in ctn.lib.ctn_last_error()
     with pytest.raises(ctn.CtnError):
         ctn.lib.call("ctn_im2col", 0, 0, 1, 100, 20, 20, 9, 64, 0)
