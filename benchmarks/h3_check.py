@@ -93,12 +93,12 @@ def run(tag, sx, sg, sw, heavy=False, per_m=False, time=True):
     # B5: dx = W1^T dh1 + dy
     ref5 = torch.einsum("cr,mck->mrk", w1.double(), gH.double()) + gB.double()
     sc5 = (torch.einsum("cr,mck->mrk", w1.double().abs(), gH.double().abs()) + gB.double().abs()).clamp_min(1e-300)
-    oam = torch.zeros(M, dtype=torch.int32, device=dev)
+    oam = torch.zeros(M, 64, dtype=torch.int32, device=dev)
     line("B5 dgrad + residual", [("h3", lambda: ops.pw_gemm_h3(q1, gH, B, H, K, agH, residual=gB, out_amax=oam)[0]),
                                  ("b6", with_arith(2, lambda: ops.pw_gemm(w1, gH, B, H, K, trans_w=True, residual=gB)[0])),
                                  ("fp32", with_arith(0, lambda: ops.pw_gemm(w1, gH, B, H, K, trans_w=True, residual=gB)[0]))], ref5, sc5, time)
     true_am = ref5.float().abs().amax((1, 2))
-    got_am = oam.view(torch.float32)
+    got_am = oam.view(torch.float32).amax(1)
     print("   out_amax vs max |fp64 result|: max rel diff %.2e" % ((got_am - true_am).abs() / true_am).max().item())
     # B1: dn2 = W2^T dy (+ gLN backward sums)
     pre = torch.where(xH >= 0, xH, 0.25 * xH).double()

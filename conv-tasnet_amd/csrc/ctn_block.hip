@@ -167,7 +167,7 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.slab = o; o += align256(w.slab_bytes);
     w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);         // [nblocks][w2 operand (H rows) | w1 operand (B rows)], b3 pieces
     w.gb = o; o += align256((size_t)nblocks * 2 * sizeof(float));   // h3: {max |gamma2|, max |beta2|} per block
-    w.amax = o; o += align256((size_t)nblocks * 2 * M * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block and utterance
+    w.amax = o; o += align256((size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block and utterance
     w.total = o;
     return w;
 }
@@ -207,7 +207,7 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
     float* const gb = (float*)((char*)workspace + w.gb);
     if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, h3, gb, stream))) return rc;
     if (h3) {       // range tracking: every slot starts at 0; the stack's input is measured here, everything else by its producer
-        if (hipMemsetAsync(amax, 0, (size_t)nblocks * 2 * M * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+        if (hipMemsetAsync(amax, 0, (size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
             ctn_set_error("ctn_tcn_gln_fwd: hipMemsetAsync failed");
             return CTN_ERR_LAUNCH;
         }
@@ -240,8 +240,8 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
                 const size_t xo = (size_t)m0 * B * Kp, ho = (size_t)m0 * H * Kp;
                 double* const s1 = st1 + (size_t)m0 * w.np1 * 2;
                 double* const s2 = st2 + (size_t)m0 * H * 2;
-                unsigned* const ax = h3 ? amax + (size_t)(2 * i) * M + m0 : nullptr;        // max |x_in|, max |d| of this block
-                unsigned* const ad = h3 ? amax + (size_t)(2 * i + 1) * M + m0 : nullptr;
+                unsigned* const ax = h3 ? amax + ((size_t)(2 * i) * M + m0) * CTN_AMAX_SLOTS : nullptr;        // max |x_in|, max |d| of this block
+                unsigned* const ad = h3 ? amax + ((size_t)(2 * i + 1) * M + m0) * CTN_AMAX_SLOTS : nullptr;
                 if (h3) {
                     if (step == 0)
                         rc = PROBED(F_K1, st, ctn_pw_gemm_h3(w1t, xin + xo, h1 + ho, Mc, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -251,7 +251,7 @@ int ctn_tcn_gln_fwd(const void* const* params, const int* dilation, int nblocks,
                                                          ms1 + 2 * m0, p[P_A2], s2, ad, st));
                     else
                         rc = PROBED(F_K3, st, ctn_pw_gemm_h3(w2t, d + ho, out + xo, Mc, B, H, K, Kp, s2, H, p[P_G2], p[P_B2], p[P_A2], ms2 + 2 * m0, xin + xo,
-                                                             nullptr, nullptr, ad, gb + 2 * i, i + 1 < nblocks ? amax + (size_t)(2 * i + 2) * M + m0 : nullptr, st));
+                                                             nullptr, nullptr, ad, gb + 2 * i, i + 1 < nblocks ? amax + ((size_t)(2 * i + 2) * M + m0) * CTN_AMAX_SLOTS : nullptr, st));
                 } else if (step == 0)
                     rc = PROBED(F_K1, st, ctn_pw_gemm(w1t, xin + xo, h1 + ho, Mc, H, B, K, Kp, tw1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                                                       p[P_A1], s1, 0, st));
@@ -301,11 +301,11 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     unsigned* const amax_b = (unsigned*)(ws + w.amax);          // [nblocks][dy | dh1][M]
     if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, h3, gb, stream))) return rc;
     if (h3) {
-        if (hipMemsetAsync(amax_b, 0, (size_t)nblocks * 2 * M * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+        if (hipMemsetAsync(amax_b, 0, (size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
             ctn_set_error("ctn_tcn_gln_bwd: hipMemsetAsync failed");
             return CTN_ERR_LAUNCH;
         }
-        if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M, stream)))) return rc;
+        if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
     }
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
@@ -313,10 +313,10 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
         const float* const h1 = h1s + (size_t)i * hsz;
         const float* const d = ds + (size_t)i * hsz;
-        const unsigned* const ax = h3 ? amax + (size_t)(2 * i) * M : nullptr;           // forward: max |x_in|, max |d|
-        const unsigned* const ad = h3 ? amax + (size_t)(2 * i + 1) * M : nullptr;
-        unsigned* const ady = amax_b + (size_t)(2 * i) * M;                             // backward: max |dy|, max |dh1|
-        unsigned* const adh = amax_b + (size_t)(2 * i + 1) * M;
+        const unsigned* const ax = h3 ? amax + (size_t)(2 * i) * M * CTN_AMAX_SLOTS : nullptr;           // forward: max |x_in|, max |d|
+        const unsigned* const ad = h3 ? amax + (size_t)(2 * i + 1) * M * CTN_AMAX_SLOTS : nullptr;
+        unsigned* const ady = amax_b + (size_t)(2 * i) * M * CTN_AMAX_SLOTS;                             // backward: max |dy|, max |dh1|
+        unsigned* const adh = amax_b + (size_t)(2 * i + 1) * M * CTN_AMAX_SLOTS;
         const float* const ms1 = ms + ((size_t)i * 2 + 0) * M * 2;
         const float* const ms2 = ms + ((size_t)i * 2 + 1) * M * 2;
         const float* const dy = i == nblocks - 1 ? dout : dxs + (size_t)(i + 1) * xsz;   // gradient of this block's output
@@ -358,7 +358,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = finalize(wst))) return rc;
         }
         if (h3) rc = PROBED(F_B5, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i + 1) * slot, dn1, dx, M, B, H, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy,
-                         nullptr, nullptr, adh, nullptr, i > 0 ? amax_b + (size_t)(2 * i - 2) * M : nullptr, stream));
+                         nullptr, nullptr, adh, nullptr, i > 0 ? amax_b + (size_t)(2 * i - 2) * M * CTN_AMAX_SLOTS : nullptr, stream));
         else rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
                          nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
         if (rc) return rc;

@@ -66,16 +66,27 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
     return r;
 }
 
-// Maximum of |v| over a block, merged into *dst (bit pattern of a non-negative float: unsigned order = float order; NaN
-// patterns compare above every number, so a NaN anywhere poisons the maximum, as it should).  max is exact and order-free:
-// the atomic keeps results bitwise reproducible.  `scratch` holds >= NT/64 doubles.
+// Range tracking for the h3 GEMM arithmetic.  The maximum of |x| over one utterance's tensor lives in CTN_AMAX_SLOTS unsigned
+// words (bit patterns of non-negative floats: unsigned order = float order); a producer workgroup merges its block maximum into
+// ONE of them with an atomic max (slot = its index within the utterance mod 64 -- 128..1024 atomics per launch on ONE address
+// cost the producers 5-9 us, profiles/README.md), a consumer takes the maximum over the 64.  max is exact and order-free, so
+// results stay bitwise reproducible.  `scratch` holds >= NT/64 doubles.
+#ifndef CTN_AMAX_SLOTS
+#define CTN_AMAX_SLOTS 64
+#endif
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+__device__ __forceinline__ float amax_read(const unsigned* __restrict__ slots) {     // every lane returns the maximum
+    unsigned b = slots[threadIdx.x & 63];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
+    return __uint_as_float(b);
+}
 template <int NT>
-__device__ __forceinline__ void block_amax_atomic(float v, double* scratch, unsigned* dst) {
+__device__ __forceinline__ void block_amax_atomic(float v, double* scratch, unsigned* slots, int slot) {
     constexpr int NW = NT / 64;
     unsigned b = __float_as_uint(fabsf(v));
 #pragma unroll
@@ -88,7 +99,7 @@ __device__ __forceinline__ void block_amax_atomic(float v, double* scratch, unsi
         unsigned r = sc[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) r = r > sc[w] ? r : sc[w];
-        if (r != 0u) atomicMax(dst, r);
+        if (r != 0u) atomicMax(slots + (slot & (CTN_AMAX_SLOTS - 1)), r);
     }
 }
 

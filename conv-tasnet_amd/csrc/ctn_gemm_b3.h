@@ -27,6 +27,7 @@
 // Included by ctn_gemm.hip (the argument structs live in that translation unit's anonymous namespace).
 #pragma once
 #include "ctn_gemm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -55,13 +56,14 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {          // round
 }
 // `s` (h3 only): the operand's power-of-two scale.  The 16-bit containers are declared bf16x4 / bf16x8 for every arithmetic
 // (LDS traffic and fragment moves do not look at the format); only the split and the MFMA know what the bits mean.
-template <int AR>
+// PRESCALED: v already carries the scale (folded into the operand prologue's constants: a power of two commutes with rounding).
+template <int AR, bool PRESCALED = false>
 __device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[Ar<AR>::NP], float s) {
     static_assert(AR == 2 || AR == 3 || AR == 4, "b3, b6 or h3");
     if constexpr (Ar<AR>::F16) {
         // a s = a0 + a1 + r:  a0 = f16_rne(a s), a1 = f16_rne(a s - a0) (the difference is exact in fp32), |r| <= 2^-24 |a s| as
         // long as a1 is a normal fp16 number, |r| <= 2^-25 (half an fp16 subnormal step) below that
-        const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+        const float x0 = PRESCALED ? v.x : v.x * s, x1 = PRESCALED ? v.y : v.y * s, x2 = PRESCALED ? v.z : v.z * s, x3 = PRESCALED ? v.w : v.w * s;
         const unsigned h0 = pk_f16(x0, x1), h1 = pk_f16(x2, x3);
         const f32x2v w0 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h0), f32x2v);
         const f32x2v w1 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h1), f32x2v);
@@ -96,15 +98,14 @@ __device__ __forceinline__ float h3_pro_bound(float amax, float alpha, float mea
     const float pa = fmaxf(1.f, fabsf(alpha)) * amax;
     return gbmax[0] * fabsf(rstd) * (pa + fabsf(mean)) + gbmax[1];
 }
-// acc *= 2^-(ea + eb), as two factors of about half the exponent each (every intermediate stays in range whenever the result does)
+// acc *= 2^-(ea + eb): v_ldexp_f32 (exact; overflows / underflows only where the result itself does)
 template <int N>
 __device__ __forceinline__ void h3_unscale(f32x16 (&acc)[N], int ea, int eb) {
-    const int t = -(ea + eb), t1 = t / 2;
-    const float f1 = h3_pow2(t1), f2 = h3_pow2(t - t1);
+    const int t = -(ea + eb);
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = (acc[i][e] * f1) * f2;
+        for (int e = 0; e < 16; ++e) acc[i][e] = __builtin_amdgcn_ldexpf(acc[i][e], t);
 }
 
 // The piece products of one 16-deep step in issue order, smallest terms first: (piece of A, piece of B).
@@ -347,8 +348,8 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     int eg = 0, ex = 0;
     float sg = 1.f, sx = 1.f;
     if constexpr (Ar<AR>::F16) {
-        eg = h3_exp(__uint_as_float(a.g_amax[m]));
-        const float xm = __uint_as_float(a.x_amax[m]);
+        eg = h3_exp(amax_read(a.g_amax + (size_t)m * CTN_AMAX_SLOTS));
+        const float xm = amax_read(a.x_amax + (size_t)m * CTN_AMAX_SLOTS);
         ex = h3_exp(PRO == PRO_PRELU_NORM ? h3_pro_bound(xm, p_alpha, p_mean, p_rstd, a.pro_gbmax) : xm);
         sg = h3_pow2(eg);
         sx = h3_pow2(ex);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int c = c0 + (tid >> 3) + 64 * j;
-            rg[j] = c < a.Cn ? make_float2(a.pro_gamma[c], a.pro_beta[c]) : make_float2(0.f, 0.f);
+            rg[j] = c < a.Cn ? make_float2(a.pro_gamma[c] * sx, a.pro_beta[c] * sx) : make_float2(0.f, 0.f);     // (h3: the scale rides in the constants)
         }
     }
     const int nk = (ke - kb + XK - 1) / XK;
@@ -379,9 +380,9 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
             qb[j] = buf_ld4(rsX, (int)((unsigned)(((c0 + row) * a.Kp + k) * 4) + oob), 0);
         }
     };
-    auto write_one = [&](__bf16* P, int row, const float4& v, float sc) {
+    auto write_one = [&](__bf16* P, int row, const float4& v, float sc, auto prescaled) {
         bf16x4 q[NP];
-        split_x4<AR>(v, q, sc);
+        split_x4<AR, decltype(prescaled)::value>(v, q, sc);
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(P + p * PLANE + row * XPA + kq) = q[p];
     };
@@ -389,11 +390,11 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (tid >> 3) + 64 * j;
-            write_one(Ap + stage * STAGE, row, qa[j], sg);
+            write_one(Ap + stage * STAGE, row, qa[j], sg, std::false_type{});
             float4 x = qb[j];
             // (frames past the chunk end are frames >= Kp >= K: the prologue zeroes them like every frame >= K)
             if constexpr (PRO == PRO_PRELU_NORM) x = pro_apply(x, kb + kt * XK + kq, a.K, rg[j].x, rg[j].y, p_alpha, p_mean, p_rstd);
-            write_one(Bp + stage * STAGE, row, x, sx);
+            write_one(Bp + stage * STAGE, row, x, sx, std::integral_constant<bool, PRO == PRO_PRELU_NORM>{});
         }
     };
 
@@ -547,7 +548,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     float sx = 1.f;
     if constexpr (Ar<AR>::F16) {
         ew = h3_exp(__uint_as_float(*reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(a.W) + (size_t)Rp * Cnp * (2 * NP))));
-        const float xm = __uint_as_float(a.x_amax[m]);
+        const float xm = amax_read(a.x_amax + (size_t)m * CTN_AMAX_SLOTS);
         ex = h3_exp(PRO == PRO_PRELU_NORM ? h3_pro_bound(xm, p_alpha, p_mean, p_rstd, a.pro_gbmax) : xm);
         sx = h3_pow2(ex);
     }
@@ -598,13 +599,16 @@ void pw_gemm_b3p_kernel(PwArgs a) {
         for (int j = 0; j < B_L; ++j) {
             const int i = tid / (TN / 4) + (4 * NTH / TN) * j, k = (tid % (TN / 4)) * 4;
             float4 v = rb[j];
-            if constexpr (PRO == PRO_PRELU_NORM) v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
+            if constexpr (PRO == PRO_PRELU_NORM) {
+                if constexpr (Ar<AR>::F16) v = pro_apply(v, c0 + k, a.K, rp[j].x * sx, rp[j].y * sx, p_alpha, p_mean, p_rstd);
+                else v = pro_apply(v, c0 + k, a.K, rp[j].x, rp[j].y, p_alpha, p_mean, p_rstd);
+            }
             bf16x4 q[NP];
 #ifdef CTN_EXP_B3_NOSPLIT
             q[0] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
             for (int p = 1; p < NP; ++p) q[p] = q[0];
 #else
-            split_x4<AR>(v, q, sx);
+            split_x4<AR, PRO == PRO_PRELU_NORM>(v, q, sx);
 #endif
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(S + (p * XK + i) * PB + k) = q[p];
@@ -725,31 +729,37 @@ struct AbsmaxArgs {
     unsigned* dst[SPLIT_MAX];
     int n;
 };
-__global__ __launch_bounds__(256) void absmax_batch_kernel(AbsmaxArgs a) {
-    __shared__ unsigned sc[4];
+__global__ __launch_bounds__(1024) void absmax_batch_kernel(AbsmaxArgs a) {
+    __shared__ unsigned sc[16];
     const float* __restrict__ S = a.src[blockIdx.x];
     unsigned b = 0u;
     const int n4 = a.n & ~3;
-    for (int i = threadIdx.x * 4; i < n4; i += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(S + i);
+    auto upd = [&](const float4& v) {
         const unsigned t0 = __float_as_uint(fabsf(v.x)), t1 = __float_as_uint(fabsf(v.y));
         const unsigned t2 = __float_as_uint(fabsf(v.z)), t3 = __float_as_uint(fabsf(v.w));
         const unsigned u = (t0 > t1 ? t0 : t1), w = (t2 > t3 ? t2 : t3);
         b = b > u ? b : u;
         b = b > w ? b : w;
+    };
+    int i = threadIdx.x * 4;
+    for (; i + 3 * 4096 < n4; i += 4 * 4096) {       // four 16-byte loads in flight per thread
+        const float4 v0 = *reinterpret_cast<const float4*>(S + i), v1 = *reinterpret_cast<const float4*>(S + i + 4096);
+        const float4 v2 = *reinterpret_cast<const float4*>(S + i + 2 * 4096), v3 = *reinterpret_cast<const float4*>(S + i + 3 * 4096);
+        upd(v0); upd(v1); upd(v2); upd(v3);
     }
-    for (int i = n4 + threadIdx.x; i < a.n; i += 256) { const unsigned t = __float_as_uint(fabsf(S[i])); b = b > t ? b : t; }
+    for (; i < n4; i += 4096) upd(*reinterpret_cast<const float4*>(S + i));
+    for (int j = n4 + threadIdx.x; j < a.n; j += 1024) { const unsigned t = __float_as_uint(fabsf(S[j])); b = b > t ? b : t; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)b, o, 64); b = b > t ? b : t; }
     if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = b;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned r = sc[0];
-        for (int w = 1; w < 4; ++w) r = r > sc[w] ? r : sc[w];
+        for (int w = 1; w < 16; ++w) r = r > sc[w] ? r : sc[w];
         a.dst[blockIdx.x][0] = r;
     }
 }
-// amax[m] = max(amax[m], max |x[m][0 .. n)|) : activations entering a stack (the caller zeroes amax); n % 4 == 0, 16-byte rows
+// slots of amax[m] <- max |x[m][0 .. n)| : activations entering a stack (the caller zeroes amax); n % 4 == 0, 16-byte rows
 __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ amax) {
     __shared__ double red[4];
     const int m = blockIdx.y;
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
         v = fmaxf(fmaxf(v, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
         // (fmaxf drops NaNs; a NaN input still poisons the GEMM result through the operand itself)
     }
-    block_amax_atomic<256>(v, red, amax + m);
+    block_amax_atomic<256>(v, red, amax + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x);
 }
 
 template <int AR, typename TL>
@@ -858,7 +868,7 @@ static void ctn_b3_launch_absmax(const void* const* src, void* const* dst, size_
             aa.dst[i] = (unsigned*)((char*)dst[o + i] + dst_offset);
         }
         aa.n = len;
-        hipLaunchKernelGGL(absmax_batch_kernel, dim3(cnt), dim3(256), 0, st, aa);
+        hipLaunchKernelGGL(absmax_batch_kernel, dim3(cnt), dim3(1024), 0, st, aa);
     }
 }
 

@@ -61,9 +61,9 @@ struct PwArgs {
     const float* bwd_y; const float* bwd_gamma; const float* bwd_alpha;
     const float* bwd_ms; double* bwd_part;         // EPI_GLN_BWD
     // h3 arithmetic (ctn_gemm_b3.h): range information of the operands, all optional elsewhere
-    const unsigned* x_amax;   // [M] bit pattern of max |X[m]| as stored (before the prologue): scale of the B operand
+    const unsigned* x_amax;   // [M][CTN_AMAX_SLOTS] max |X[m]| as stored (before the prologue): scale of the B operand
     const float* pro_gbmax;   // {max |gamma|, max |beta|} of the prologue's norm
-    unsigned* out_amax;       // EPI_RESIDUAL: [M] atomic max of |Out[m]| (caller zeroes it), for the GEMMs that read Out next
+    unsigned* out_amax;       // EPI_RESIDUAL: [M][CTN_AMAX_SLOTS] max |Out[m]| (caller zeroes it), for the GEMMs that read Out next
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     }
     if constexpr (EPI == EPI_RESIDUAL) {
         // (rows >= R / columns >= Kp never reach `amax`: the loop skips them or they are exact zeros)
-        if (a.out_amax != nullptr) block_amax_atomic<TL::NTH>(amax, red, a.out_amax + m);
+        if (a.out_amax != nullptr) block_amax_atomic<TL::NTH>(amax, red, a.out_amax + (size_t)m * CTN_AMAX_SLOTS, ct * a.tiles_r + rt);
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
         const double d1 = block_sum<double, TL::NTH>((double)s1, red);
@@ -229,7 +229,7 @@ struct WgArgs {
     int M, R, Cn, K, Kp;
     int tiles_r, tiles_c, chunk, chunks_per_m;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
-    // h3 arithmetic: [M] bit patterns of max |dOut[m]| / max |X[m]| (as stored), {max |gamma|, max |beta|} of the prologue
+    // h3 arithmetic: [M][CTN_AMAX_SLOTS] max |dOut[m]| / max |X[m]| (as stored), {max |gamma|, max |beta|} of the prologue
     const unsigned* g_amax; const unsigned* x_amax; const float* pro_gbmax;
 };
 

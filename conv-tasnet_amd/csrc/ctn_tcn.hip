@@ -37,7 +37,7 @@ struct DwFwdArgs {
     const double* pro_part; int pro_nparts;
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; float* pro_ms_out;
     const float* epi_alpha; double* epi_part;   // [M, H, 2]
-    unsigned* amax_out;                         // EPI: [M] atomic max of |Z[m]| (h3 arithmetic of the GEMM that reads Z), optional
+    unsigned* amax_out;                         // EPI: [M][CTN_AMAX_SLOTS] max |Z[m]| (h3 arithmetic of the GEMM that reads Z), optional
 };
 
 template <bool PRO, bool EPI, int FWD_BUF, bool VEC4, int PT>      // PT: compile-time kernel size (3) or 0 = a.P at run time
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             dst[0] = d1;
             dst[1] = d2;
         }
-        if (a.amax_out != nullptr) block_amax_atomic<NT>(amax, red, a.amax_out + m);      // (dead waves hold 0)
+        if (a.amax_out != nullptr) block_amax_atomic<NT>(amax, red, a.amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % hb);      // (dead waves hold 0)
     }
 }
 
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(NT) void gln_prelu_bwd_kernel(const float* __restri
     }
     dal = wave_sum(dal);
     if (live && lane == 0) dalpha_part[(size_t)m * H + c] = dal;
-    if (amax_out != nullptr) block_amax_atomic<NT>(amax, red, amax_out + m);
+    if (amax_out != nullptr) block_amax_atomic<NT>(amax, red, amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % hb);
 }
 
 // ---------------------------------------------------------------------------

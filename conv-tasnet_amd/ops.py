@@ -26,6 +26,7 @@ F32 = torch.float32
 F64 = torch.float64
 BF16 = torch.bfloat16
 
+AMAX_SLOTS = 64        # CTN_AMAX_SLOTS of include/ctn_hip.h
 _ARITH_NAMES = ("fp32", "b3", "b6", "h3")        # ids of ctn_gemm_arith / ctn_tune("arith", id)
 
 
@@ -169,11 +170,11 @@ def h3_pieces(W, R, Cn, k_major):
 
 
 def absmax_rows(x, out=None):
-    """int32 [M]: bit patterns of max |x[m]| (merged into `out` when given)."""
+    """int32 [M, AMAX_SLOTS]: tracked maximum of |x[m]| (bit patterns; the maximum over the slots), merged into `out` when given."""
     _chk(x)
     M = x.shape[0]
     if out is None:
-        out = torch.zeros((M,), dtype=torch.int32, device=x.device)
+        out = torch.zeros((M, AMAX_SLOTS), dtype=torch.int32, device=x.device)
     lib.call("ctn_absmax_rows", _p(x), M, x[0].numel(), _p(out), _stream())
     return out
 
@@ -585,7 +586,7 @@ def tcn_gln_infer(x0, K, dilations, causal, params):
     h1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
     d = torch.empty((M, H, Kp), dtype=F32, device=dev)
     ms = torch.empty((2, M, 2), dtype=F32, device=dev)
-    amax = torch.empty((nb, 2, M), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked operand maxima (zeroed by the call)
+    amax = torch.empty((nb, 2, M, AMAX_SLOTS), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked operand maxima (zeroed by the call)
     nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp, nb)
     ws = _workspace(nbytes, dev, "tcn_fwd")
     dil = (ctypes.c_int * nb)(*dilations)
@@ -613,7 +614,7 @@ class TcnGln(torch.autograd.Function):
         h1s = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
         ds = torch.empty((nb, M, H, Kp), dtype=F32, device=dev)
         ms = torch.empty((nb, 2, M, 2), dtype=F32, device=dev)
-        amax = torch.empty((nb, 2, M), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked maxima of every block's input / depthwise output
+        amax = torch.empty((nb, 2, M, AMAX_SLOTS), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked maxima of every block's input / depthwise output
         nbytes = lib.ctn_tcn_gln_fwd_workspace(M, B, H, Kp, nb)
         ws = _workspace(nbytes, dev, "tcn_fwd")
         dil = (ctypes.c_int * nb)(*dilations)

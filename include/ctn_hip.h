@@ -30,6 +30,7 @@ extern "C" {
 #define CTN_ERR_ARG (-1)
 #define CTN_ERR_LAUNCH (-2)
 #define CTN_ERR_WORKSPACE (-3)
+#define CTN_AMAX_SLOTS 64      /* words per utterance of a tracked-maximum array (h3 arithmetic, below) */
 
 int ctn_version(void);
 const char* ctn_last_error(void);
@@ -118,9 +119,10 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
  *   a1.b1 + r_a.b + a.r_b, <= 3 * 2^-24 |a.b| -- the size of the rounding an fp32 FMA chain commits per step (b6 drops 2 * 2^-24).
  * fp16 has 5 exponent bits, so every operand is brought into range by an exact power-of-two scale s derived from a bound on
  * its magnitude: the weight's own maximum (computed by ctn_split_h3_batch), and for activations the per-utterance maximum
- * max |X[m]| TRACKED BY THE KERNEL THAT PRODUCED X -- `amax` arrays: [M] unsigned, the bit pattern of a non-negative float,
- * merged with atomic max (exact, order-free: results stay bitwise reproducible); the caller zeroes them before the producer
- * runs.  Producers: ctn_absmax_rows (any tensor), ctn_pw_gemm_h3 (residual epilogue, out_amax), ctn_dw_fwd and
+ * max |X[m]| TRACKED BY THE KERNEL THAT PRODUCED X -- `amax` arrays: [M][CTN_AMAX_SLOTS] unsigned, bit patterns of non-negative
+ * floats; a producer workgroup merges its maximum into one of an utterance's slots with an atomic max (exact, order-free: results
+ * stay bitwise reproducible; 64 slots because 1000 atomics on one address cost a producer 5-9 us), a consumer takes the maximum
+ * over the slots; the caller zeroes the array before the producer runs.  Producers: ctn_absmax_rows (any tensor), ctn_pw_gemm_h3 (residual epilogue, out_amax), ctn_dw_fwd and
  * ctn_gln_prelu_bwd (amax_out).  With an operand prologue the scale comes from the bound
  * max|gamma| * rstd * (max(1,|alpha|) * amax + |mean|) + max|beta|  (pro_gbmax = {max|gamma|, max|beta|}: ctn_absmax_batch).
  * Scaled values stay below 2^14 (fp16 holds 65504).  Elements within 2^-17 of their utterance's maximum keep the full
@@ -131,9 +133,9 @@ size_t ctn_split_h3_bytes(int R, int Cn);
 int ctn_split_h3_batch(const void* const* src, void* const* dst, int n, int R, int Cn, int k_major, void* stream);
 /* dst[i][0] = bit pattern of max |src[i][0 .. len)|  (HOST arrays of device pointers; dst[i]: 4 bytes) */
 int ctn_absmax_batch(const void* const* src, void* const* dst, int n, int len, void* stream);
-/* amax[m] = max(amax[m], bits of max |x[m][0 .. n)|),  x: [M, n] fp32, n % 4 == 0 */
+/* slots of amax[m] <- bits of max |x[m][0 .. n)|,  x: [M, n] fp32, n % 4 == 0, amax: [M][CTN_AMAX_SLOTS] */
 int ctn_absmax_rows(const float* x, int M, long long n, unsigned* amax, void* stream);
-/* ctn_pw_gemm(trans_w = 2) on h3 pieces.  x_amax [M]: maximum of X as stored; pro_gbmax with the prologue; out_amax [M]
+/* ctn_pw_gemm(trans_w = 2) on h3 pieces.  x_amax: maximum of X as stored; pro_gbmax with the prologue; out_amax
  * (optional, with residual): receives the maximum of Out. */
 int ctn_pw_gemm_h3(const void* Wp, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
                    const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
@@ -156,7 +158,7 @@ size_t ctn_pw_wgrad_h3_workspace(int M, int R, int Cn, int Kp);
  *   pad_left = (P-1)*dilation/2 (non-causal "same") or (P-1)*dilation (causal, = pad + Chomp1d).
  *   pro_part != NULL: n = gLN(prelu(Y)) as in ctn_pw_gemm; else n = Y.
  *   epi_part != NULL: partials of prelu(Z, epi_alpha), layout [M, H, 2] fp64;
- *   amax_out != NULL (with epi_part): amax_out[m] = max(amax_out[m], bits of max |Z[m]|) -- see the h3 section. */
+ *   amax_out != NULL (with epi_part): [M][CTN_AMAX_SLOTS], receives max |Z[m]| -- see the h3 section. */
 int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
                const double* pro_part, int pro_nparts, const float* pro_gamma, const float* pro_beta,
                const float* pro_alpha, float* pro_ms_out, const float* epi_alpha, double* epi_part, unsigned* amax_out,
@@ -188,7 +190,7 @@ int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* strea
 
 /* dY = rstd*(gamma*dN - S1/n - xhat*S2/n) * prelu'(Y);  dalpha_part [M*H] = per-row sum over Y<0 of (..)*Y.
  * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN.
- * amax_out != NULL: amax_out[m] = max(amax_out[m], bits of max |dY[m]|) -- see the h3 section. */
+ * amax_out != NULL: [M][CTN_AMAX_SLOTS], receives max |dY[m]| -- see the h3 section. */
 int ctn_gln_prelu_bwd(const float* dN, const float* Y, float* dY, int M, int H, int K, int Kp,
                       const float* gamma, const float* alpha, const float* ms, const double* sums_part, int nparts,
                       float* dalpha_part, unsigned* amax_out, void* stream);
@@ -213,7 +215,7 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
  *     xs  [nblocks][M,B,Kp]  block outputs (xs[nblocks-1] is the stack's output),
  *     h1s [nblocks][M,H,Kp]  first 1x1 outputs,  ds [nblocks][M,H,Kp] depthwise outputs,
  *     ms  [nblocks][2][M][2] (mean, rstd) of the two gLNs,
- *     amax [nblocks][2][M] unsigned (h3 arithmetic; may be NULL otherwise): the tracked maxima of every block's input and of
+ *     amax [nblocks][2][M][CTN_AMAX_SLOTS] unsigned (h3 arithmetic; may be NULL otherwise): the tracked maxima of every block's input and of
  *          its depthwise output (see the h3 section); written by the forward pass (which zeroes it first), read by backward.
  *     save = 0 (inference): xs needs 2 slots, h1s / ds / ms one slot each (amax all nblocks); the output is xs[(nblocks-1) & 1].
  *   forward with side_stream != NULL and M >= 2: the batch runs as two half-batch chains on the two streams (utterances are
