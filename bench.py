@@ -33,9 +33,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
                                # benchmarks/mfma_probe.hip, profiles/r02_a_mfma_probe.txt)
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0          # same guide, HBM3E peak
-ARITH = {"name": "b6"}         # GEMM arithmetic of this run (--arith): "b6" = 6 bf16 MFMAs per product step (three bf16 pieces per
-                               # fp32 operand: fp32-faithful products, the library default), "fp32" = fp32 MFMA, "b3" = 3 bf16 MFMAs
-                               # (two pieces: ~16-bit products, opt-in, NOT reference precision)
+ARITH = {"name": "h3"}         # GEMM arithmetic of this run (--arith): "h3" (library default) = the composite stacks on two fp16 pieces per
+                               # fp32 operand under tracked power-of-two scales, 3 f16 MFMAs per product step (fp32-faithful products; every
+                               # other GEMM as b6), "b6" = three bf16 pieces, 6 bf16 MFMAs (fp32-faithful), "fp32" = fp32 MFMA,
+                               # "b3" = 3 bf16 MFMAs (two bf16 pieces: ~16-bit products, opt-in, NOT reference precision)
 ARITH_IDS = {"fp32": 0, "b3": 1, "b6": 2, "h3": 3}
 MFMA_PER_STEP = {"b3": 3, "b6": 6, "h3": 3}
 PER_GPU_BATCH = 8
@@ -202,8 +203,9 @@ def family_table(probe, stack, cfg, K, steps):
     c = cfg["model"]
     M, H = PER_GPU_BATCH, c["H"]
     hbm_bytes = {"ctn_dw_fwd": 2, "ctn_dw_bwd": 4, "ctn_gln_prelu_bwd": 3}      # tensors of M*H*K*4 bytes read + written
-    b3 = ARITH["name"] in MFMA_PER_STEP          # split-bf16 arithmetic: the 1x1 GEMMs run on the bf16 matrix cores
-    nprod = MFMA_PER_STEP.get(ARITH["name"], 1)
+    b3 = ARITH["name"] in MFMA_PER_STEP          # split arithmetics: the 1x1 GEMMs run on the bf16 / f16 matrix cores
+    nprod = MFMA_PER_STEP.get(ARITH["name"], 1)  # of the composite stacks' GEMMs
+    nprod_other = 6 if ARITH["name"] == "h3" else nprod      # GEMMs outside the stacks run as b6 under h3
     fams = {}
     B = c["B"]
     gln = cfg["norm_type"] == "gLN"
@@ -237,7 +239,7 @@ def family_table(probe, stack, cfg, K, steps):
         chains = 2.0 if (fid in (0, 1, 2, 11) and abs(per_block / (2.0 if fid == 11 else 1.0) - 2.0) < 1e-6) else 1.0
         if chains > 1.0 and "half-batch" not in name:
             name += " [two half-batch launches per block]"
-        f = fams.setdefault(name, {"bound": "mfma" if shape else "hbm", "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": "stack"})
+        f = fams.setdefault(name, {"bound": "mfma" if shape else "hbm", "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": "stack", "nprod": nprod})
         f["us"].append(us)
         f["bytes"] += nbytes / chains
         if shape:
@@ -248,7 +250,7 @@ def family_table(probe, stack, cfg, K, steps):
         if name.startswith("ctn_tcn_") or name.startswith("ctn_probe"):
             continue                                # the stacks as wholes: their launch groups are in `stack`
         fam, bound, shape = _family(name, a)
-        f = fams.setdefault(fam, {"bound": bound, "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": name})
+        f = fams.setdefault(fam, {"bound": bound, "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": name, "nprod": nprod_other})
         f["us"].append(1e3 * e0.elapsed_time(e1))
         if bound == "mfma":
             f["flops"] += 2.0 * shape[1] * shape[2] * K * shape[0]           # algorithmic FLOPs: 2*R*Cn per frame
@@ -265,14 +267,16 @@ def family_table(probe, stack, cfg, K, steps):
                "us_per_launch": round(tot / n, 2), "ms_per_step": round(tot / steps / 1e3, 3),
                "algorithmic_bytes_per_step": f["bytes"] / steps}
         if f["flops"] > 0:
-            row["executed_mfma_flops_per_step"] = f["flops"] / steps * (nprod if f["b3"] * 2 > n else 1)
+            row["executed_mfma_flops_per_step"] = f["flops"] / steps * (f["nprod"] if f["b3"] * 2 > n else 1)
             row["on_bf16_mfma"] = f["b3"] * 2 > n
         if f["flops"] > 0:
             on_b3 = f["b3"] * 2 > n
             peak = PEAK_BF16_MFMA_TFLOPS if on_b3 else PEAK_F32_MFMA_TFLOPS
-            mfma_flops = f["flops"] * (nprod if on_b3 else 1)                # executed MFMA FLOPs
+            mfma_flops = f["flops"] * (f["nprod"] if on_b3 else 1)           # executed MFMA FLOPs
             t_mfma, t_hbm = mfma_flops / (peak * 1e12), f["bytes"] / (PEAK_HBM_GBS * 1e9)
-            row["arith"] = ("%s (%d x v_mfma_f32_32x32x16_bf16 per 16-deep step)" % (ARITH["name"], nprod)) if on_b3 else "fp32 (v_mfma_f32_32x32x2_f32)"
+            h3_row = ARITH["name"] == "h3" and f["entry"] == "stack"
+            row["arith"] = ("%s (%d x v_mfma_f32_32x32x16_%s per 16-deep step)" % ("h3" if h3_row else ("b6" if ARITH["name"] == "h3" else ARITH["name"]), f["nprod"],
+                                                                                   "f16" if h3_row else "bf16")) if on_b3 else "fp32 (v_mfma_f32_32x32x2_f32)"
             row["algorithmic_tflops"] = round(f["flops"] / (tot * 1e-6) / 1e12, 2)
             row["mfma_floor_us"] = round(t_mfma / n * 1e6, 2)
             row["hbm_floor_us"] = round(t_hbm / n * 1e6, 2)
@@ -338,9 +342,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="paper")
     ap.add_argument("--arith", choices=["h3", "b6", "fp32", "b3"], default=os.environ.get("CTN_GEMM_ARITH", "h3"),
-                    help="GEMM arithmetic: b6 = three bf16 pieces per fp32 operand, six bf16 MFMAs per product step (fp32-faithful "
-                         "products; library default), fp32 = fp32-MFMA kernels, b3 = two pieces / three MFMAs (~16-bit products; "
-                         "NOT reference precision, opt-in)")
+                    help="GEMM arithmetic: h3 = the composite stacks on two fp16 pieces per fp32 operand under tracked power-of-two scales, "
+                         "three f16 MFMAs per product step (fp32-faithful products; library default), b6 = three bf16 pieces per fp32 "
+                         "operand, six bf16 MFMAs (fp32-faithful), fp32 = fp32-MFMA kernels, b3 = two bf16 pieces / three MFMAs "
+                         "(~16-bit products; NOT reference precision, opt-in)")
     ap.add_argument("--no-side-arith", action="store_true", help="skip the short runs on the other arithmetics after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -437,12 +442,12 @@ def main():
         }
         if args.arith == "fp32":       # only a run ON the fp32 MFMA is priced against its peak
             out["model_frac_of_f32_mfma_peak"] = round(value * ftrain / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)
-        else:                          # executed bf16-MFMA FLOPs of the whole step (nprod per algorithmic product) over the dense bf16 peak
+        else:                          # executed bf16 / f16 MFMA FLOPs of the whole step (nprod per algorithmic product) over the dense peak
             out["executed_mfma_frac_of_bf16_peak"] = round(MFMA_PER_STEP[args.arith] * value * ftrain / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world), 4)
     if graphed is None and not args.no_side_arith:
         # the same workload on the other arithmetics, timed the same way right after the main measurement (every rank takes
         # part): `value` above is the run's own arithmetic; these side records show, on the same box in the same process, what
-        # the bit-exact fp32 MFMA costs and what the opt-in 16-bit-product b3 arithmetic would give
+        # the other reference-precision arithmetics (bit-exact fp32 MFMA, b6) cost
         def side_run(name):
             ctn.set_gemm_arith(name)
             nref = max(3, min(args.steps, 10))
@@ -468,8 +473,8 @@ def main():
                     "ms_per_step": round(1e3 * dref / nref, 3), "steps": nref, "warmup": 2}
         side = {}
         for name, note in (("fp32", "same step with CTN_GEMM_ARITH=fp32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 products)"),
-                           ("b3", "same step with CTN_GEMM_ARITH=b3 (two bf16 pieces per operand, ~16-bit products: NOT reference "
-                                  "precision, opt-in; shown for comparison only)")):
+                           ("b6", "same step with CTN_GEMM_ARITH=b6 (three bf16 pieces per operand, six bf16 MFMAs: fp32-faithful products)"),
+                           ("h3", "same step with CTN_GEMM_ARITH=h3 (the library default)")):
             if name != args.arith:
                 r = side_run(name)
                 r["note"] = note

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""One b3 GEMM form launched N times at the paper shapes (for rocprofv3 / PMC passes).  usage: b3_only.py K1|K3|B1|B5|W1|W2 [n]"""
+"""One GEMM form of the composite stacks launched N times at the paper shapes (for rocprofv3 / PMC passes), under the library's
+arithmetic (CTN_GEMM_ARITH; h3 = the ctn_*_h3 entry points).  usage: b3_only.py K1|K3|B1|B5|W1|W2 [n]"""
 import os
 import sys
 
@@ -40,6 +41,19 @@ fns = {
     "W1": lambda: ops.pw_wgrad(xH, xB, H, B, K),
     "W2": lambda: ops.pw_wgrad(xB, xH, B, H, K, pro=(g, b, a, ms)),
 }
+if ctn.gemm_arith() == "h3":
+    P1, P2 = ops.h3_pieces(w1, H, B, False), ops.h3_pieces(w2, B, H, False)
+    Q2, Q1 = ops.h3_pieces(w2, H, B, True), ops.h3_pieces(w1, B, H, True)
+    axB, axH, gbm = ops.absmax_rows(xB), ops.absmax_rows(xH), ops.absmax_of(g, b)
+    oam = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=dev)
+    fns = {
+        "K1": lambda: ctn.lib.call("ctn_pw_gemm_h3", _p(P1), _p(xB), _p(outH), M, H, B, K, Kp, None, 0, None, None, None, None, None, _p(a), _p(part), _p(axB), None, None, sm),
+        "K3": lambda: ctn.lib.call("ctn_pw_gemm_h3", _p(P2), _p(xH), _p(outB), M, B, H, K, Kp, _p(st2), 1, _p(g), _p(b), _p(a), None, _p(xB), None, None, _p(axH), _p(gbm), _p(oam), sm),
+        "B1": lambda: ctn.lib.call("ctn_pw_dgrad_gln_h3", _p(Q2), _p(xB), _p(outH), M, H, B, K, Kp, _p(xH), _p(g), _p(a), _p(ms), _p(part), _p(axB), sm),
+        "B5": lambda: ctn.lib.call("ctn_pw_gemm_h3", _p(Q1), _p(xH), _p(outB), M, B, H, K, Kp, None, 0, None, None, None, None, _p(xB), None, None, _p(axH), None, _p(oam), sm),
+        "W1": lambda: ops.pw_wgrad_h3(xH, xB, H, B, K, axH, axB),
+        "W2": lambda: ops.pw_wgrad_h3(xB, xH, B, H, K, axB, axH, pro=(g, b, a, ms), gbmax=gbm),
+    }
 fn = fns[form]
 for _ in range(n):
     fn()

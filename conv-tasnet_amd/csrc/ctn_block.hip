@@ -115,7 +115,7 @@ int prepare_weights(const void* const* params, int nblocks, int B, int H, bool b
             *tw = -1;       // use the stored matrix (trans_w = 1)
         }
     }
-    if (h3) {
+    if (h3 && gb != nullptr) {      // (the cLN stacks have no operand prologue)
         std::vector<const void*> gsrc(2 * (size_t)nblocks);
         std::vector<void*> gdst(2 * (size_t)nblocks);
         for (int i = 0; i < nblocks; ++i) {
@@ -378,7 +378,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
 // ---- cLN stack (causal BASELINE config): the same host-side composite over the un-fused norm kernels ------------------
 namespace {
 struct ClnBwdWs {
-    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, total, slab_bytes, pcw_slot, pcn_slot, dap_slot;
+    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, amax, total, slab_bytes, pcw_slot, pcn_slot, dap_slot;
 };
 ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     ClnBwdWs w;
@@ -399,6 +399,7 @@ ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.slab_bytes = s1 > s2 ? s1 : s2;
     w.slab = o; o += align256(w.slab_bytes);
     w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);
+    w.amax = o; o += align256((size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block
     w.total = o;
     return w;
 }
@@ -413,10 +414,12 @@ size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) {
 size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks) { return cln_bwd_ws(M, B, H, Kp, P, nblocks).total; }
 
 int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
-                    float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
+                    float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, unsigned* amax, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
     CTN_REQUIRE(params && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && workspace, "ctn_tcn_cln_fwd: null pointer");
+    const bool h3 = use_h3(B, H);
+    CTN_REQUIRE(!h3 || amax, "ctn_tcn_cln_fwd: the h3 arithmetic needs the amax array");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_fwd: bad sizes");
     if (workspace_bytes < ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nblocks)) {
         ctn_set_error("ctn_tcn_cln_fwd: workspace too small");
@@ -428,7 +431,14 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
     int rc, tw1 = 0, tw2 = 0;
     for (int i = 0; i < nblocks; ++i)
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(params[(size_t)i * NPARAM + j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
-    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, false, nullptr, stream))) return rc;
+    if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, h3, nullptr, stream))) return rc;
+    if (h3) {
+        if (hipMemsetAsync(amax, 0, (size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+            ctn_set_error("ctn_tcn_cln_fwd: hipMemsetAsync failed");
+            return CTN_ERR_LAUNCH;
+        }
+        if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(x0, M, (long long)B * Kp, amax, stream)))) return rc;
+    }
     // two half-batch chains on two streams, as in ctn_tcn_gln_fwd (cLN statistics are per frame of one utterance)
     const int nch = (side_stream != nullptr && M >= 2) ? 2 : 1;
     const int m0c[2] = {0, M / 2}, mcc[2] = {nch == 2 ? M / 2 : M, M - M / 2};
@@ -446,16 +456,25 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
                 const int m0 = m0c[c], Mc = mcc[c];
                 void* const sc = sts[c];
                 const size_t xo = (size_t)m0 * B * Kp, ho = (size_t)m0 * H * Kp, so = (size_t)m0 * Kp;
-                if (step == 0)
+                unsigned* const ax = h3 ? amax + ((size_t)(2 * i) * M + m0) * CTN_AMAX_SLOTS : nullptr;        // max |x_in|, max |n2| of this block
+                unsigned* const an = h3 ? amax + ((size_t)(2 * i + 1) * M + m0) * CTN_AMAX_SLOTS : nullptr;
+                if (step == 0 && h3)
+                    rc = PROBED(F_K1, sc, ctn_pw_gemm_h3(wreg + (size_t)(2 * i) * slot, xin + xo, h1 + ho, Mc, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr,
+                                                         nullptr, nullptr, nullptr, nullptr, ax, nullptr, nullptr, sc));
+                else if (step == 0)
                     rc = PROBED(F_K1, sc, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i) * slot), xin + xo, h1 + ho, Mc, H, B, K, Kp, tw1, nullptr, 0, nullptr,
                                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sc));
                 else if (step == 1)
-                    rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(h1 + ho, n1 + ho, stb + so, stb + ssz + so, Mc, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], sc));
+                    rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(h1 + ho, n1 + ho, stb + so, stb + ssz + so, Mc, H, K, Kp, p[P_G1], p[P_B1], p[P_A1], nullptr, sc));
                 else if (step == 2)
                     rc = PROBED(F_K2, sc, ctn_dw_fwd(n1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, nullptr, 0, nullptr, nullptr, nullptr,
                                                      nullptr, nullptr, nullptr, nullptr, sc));
                 else if (step == 3)
-                    rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(d + ho, n2 + ho, stb + 2 * ssz + so, stb + 3 * ssz + so, Mc, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], sc));
+                    rc = PROBED(F_CLN_FWD, sc, ctn_cln_fwd(d + ho, n2 + ho, stb + 2 * ssz + so, stb + 3 * ssz + so, Mc, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], an, sc));
+                else if (h3)
+                    rc = PROBED(F_K3, sc, ctn_pw_gemm_h3(wreg + (size_t)(2 * i + 1) * slot, n2 + ho, out + xo, Mc, B, H, K, Kp, nullptr, 0, nullptr, nullptr, nullptr,
+                                                         nullptr, xin + xo, nullptr, nullptr, an, nullptr,
+                                                         i + 1 < nblocks ? amax + ((size_t)(2 * i + 2) * M + m0) * CTN_AMAX_SLOTS : nullptr, sc));
                 else
                     rc = PROBED(F_K3, sc, ctn_pw_gemm((const float*)(wreg + (size_t)(2 * i + 1) * slot), n2 + ho, out + xo, Mc, B, H, K, Kp, tw2, nullptr, 0,
                                                       nullptr, nullptr, nullptr, nullptr, xin + xo, nullptr, nullptr, 0, sc));
@@ -468,11 +487,13 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
 
 int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
                     const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
-                    const float* st, const float* dout, float* dxs, float* dh1s,
+                    const float* st, const unsigned* amax, const float* dout, float* dxs, float* dh1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags) {
     CTN_REQUIRE(params && grads && dilation && nblocks > 0 && x0 && xs && h1s && n1s && ds && n2s && st && dout && dxs && dh1s && workspace,
                 "ctn_tcn_cln_bwd: null pointer");
+    const bool h3 = use_h3(B, H);
+    CTN_REQUIRE(!h3 || amax, "ctn_tcn_cln_bwd: the h3 arithmetic needs the forward pass's amax array");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_bwd: bad sizes");
     const ClnBwdWs w = cln_bwd_ws(M, B, H, Kp, P, nblocks);
     if (workspace_bytes < w.total) {
@@ -493,11 +514,23 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     char* const wreg = ws + w.wp;
     const size_t slot = wslot_bytes(B, H);
     int twh = -1, twb = -1;
-    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, false, nullptr, stream))) return rc;
+    if ((rc = prepare_weights(params, nblocks, B, H, true, wreg, slot, &twh, &twb, h3, nullptr, stream))) return rc;
+    unsigned* const amax_b = (unsigned*)(ws + w.amax);          // [nblocks][dy | dh1][M][slots]
+    if (h3) {
+        if (hipMemsetAsync(amax_b, 0, (size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+            ctn_set_error("ctn_tcn_cln_bwd: hipMemsetAsync failed");
+            return CTN_ERR_LAUNCH;
+        }
+        if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
+    }
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
         const float* const x = i == 0 ? x0 : xs + (size_t)(i - 1) * xsz;
+        const unsigned* const ax = h3 ? amax + (size_t)(2 * i) * M * CTN_AMAX_SLOTS : nullptr;           // forward: max |x_in|, max |n2|
+        const unsigned* const an = h3 ? amax + (size_t)(2 * i + 1) * M * CTN_AMAX_SLOTS : nullptr;
+        unsigned* const ady = amax_b + (size_t)(2 * i) * M * CTN_AMAX_SLOTS;                             // backward: max |dy|, max |dh1|
+        unsigned* const adh = amax_b + (size_t)(2 * i + 1) * M * CTN_AMAX_SLOTS;
         const float* const h1 = h1s + (size_t)i * hsz; const float* const n1 = n1s + (size_t)i * hsz;
         const float* const d = ds + (size_t)i * hsz; const float* const n2 = n2s + (size_t)i * hsz;
         const float* const stb = st + (size_t)i * 4 * ssz;
@@ -507,24 +540,36 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         float* const pcw = (float*)(ws + w.pcw + (size_t)i * w.pcw_slot);
         float* const pcn2 = (float*)(ws + w.pcn + (size_t)(2 * i) * w.pcn_slot), * const pcn1 = (float*)(ws + w.pcn + (size_t)(2 * i + 1) * w.pcn_slot);
         float* const dap2 = (float*)(ws + w.dap + (size_t)(2 * i) * w.dap_slot), * const dap1 = (float*)(ws + w.dap + (size_t)(2 * i + 1) * w.dap_slot);
-        if ((rc = PROBED(F_B1, stream, ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
-                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream)))) return rc;
+        if (h3) rc = PROBED(F_B1, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, ady, nullptr, nullptr, stream));
+        else rc = PROBED(F_B1, stream, ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream));
+        if (rc) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        if ((rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
-        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, stream)))) return rc;
+        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, ady, an, nullptr, slab, w.slab_bytes, wst));
+        else rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
+        if (rc) return rc;
+        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, nullptr, stream)))) return rc;
         if ((rc = PROBED(F_B3, stream, ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream)))) return rc;
-        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, stream)))) return rc;
+        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, h3 ? adh : nullptr, stream)))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         // the three fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
         void* const fst = wst;
         if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
         if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
         if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst)))) return rc;
-        if (side_stream && (rc = PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
-        if ((rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
-                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream)))) return rc;
-        if (!side_stream && (rc = PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst)))) return rc;
+        auto wgrad1 = [&]() -> int {
+            if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slab, w.slab_bytes, wst));
+            return PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
+        };
+        if (side_stream && (rc = wgrad1())) return rc;
+        if (h3) rc = PROBED(F_B5, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i + 1) * slot, dh1, dx, M, B, H, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy,
+                              nullptr, nullptr, adh, nullptr, i > 0 ? amax_b + (size_t)(2 * i - 2) * M * CTN_AMAX_SLOTS : nullptr, stream));
+        else rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
+        if (rc) return rc;
+        if (!side_stream && (rc = wgrad1())) return rc;
     }
     // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
     // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)

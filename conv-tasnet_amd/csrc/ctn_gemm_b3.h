@@ -34,9 +34,18 @@ namespace {
 constexpr int XK = 32;               // contraction steps per k-tile (two MFMA steps of depth 16)
 constexpr int XPA = XK + 8;          // row pitch of a row-major piece plane in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
 
-// Arithmetic ids of the kernels below (template parameter AR): 2 = b3, 3 = b6 (NP = AR bf16 pieces), 4 = h3 (two fp16 pieces).
-template <int AR> struct Ar { static constexpr int NP = AR; static constexpr bool F16 = false; };
-template <> struct Ar<4> { static constexpr int NP = 2; static constexpr bool F16 = true; };
+// Arithmetic ids of the kernels below (template parameter AR): 2 = b3, 3 = b6 (NP = AR bf16 pieces), 4 / 5 = h3 (two fp16 pieces).
+// 5 (the one built into the library, CTN_H3_AR) stores the low piece multiplied by 2^11 and sums the two cross products in an
+// accumulator of their own (W2): the low piece then stays a NORMAL fp16 number for every element down to 2^-27 of its operand's
+// bound instead of 2^-16 (id 4: both pieces at one scale, one accumulator -- kept for A/B builds, -DCTN_H3_AR=4).
+template <int AR> struct Ar { static constexpr int NP = AR; static constexpr bool F16 = false, W2 = false; };
+template <> struct Ar<4> { static constexpr int NP = 2; static constexpr bool F16 = true, W2 = false; };
+template <> struct Ar<5> { static constexpr int NP = 2; static constexpr bool F16 = true, W2 = true; };
+#ifndef CTN_H3_AR
+#define CTN_H3_AR 5
+#endif
+constexpr int H3AR = CTN_H3_AR;
+constexpr float H3_LOW = 2048.f;          // 2^11: scale of the low piece under W2
 
 // four consecutive fp32 -> NP bf16x4 pieces, most significant first (round-to-nearest-even each time; the differences are exact).
 // Written on packed pairs: one v_cvt_pk_bf16_f32 per pair and piece, the bf16 -> fp32 widening as a shift / mask of the packed
@@ -59,15 +68,18 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {          // round
 // PRESCALED: v already carries the scale (folded into the operand prologue's constants: a power of two commutes with rounding).
 template <int AR, bool PRESCALED = false>
 __device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[Ar<AR>::NP], float s) {
-    static_assert(AR == 2 || AR == 3 || AR == 4, "b3, b6 or h3");
+    static_assert(AR >= 2 && AR <= 5, "b3, b6 or h3");
     if constexpr (Ar<AR>::F16) {
         // a s = a0 + a1 + r:  a0 = f16_rne(a s), a1 = f16_rne(a s - a0) (the difference is exact in fp32), |r| <= 2^-24 |a s| as
-        // long as a1 is a normal fp16 number, |r| <= 2^-25 (half an fp16 subnormal step) below that
+        // long as a1 is a normal fp16 number, |r| <= 2^-25 (half an fp16 subnormal step) below that.  W2: the stored low piece
+        // is 2^11 a1 (|a s - a0| <= 2^-11 |a s|, so it stays below the scaled bound): normal for |a s| >= 2^-13
         const float x0 = PRESCALED ? v.x : v.x * s, x1 = PRESCALED ? v.y : v.y * s, x2 = PRESCALED ? v.z : v.z * s, x3 = PRESCALED ? v.w : v.w * s;
         const unsigned h0 = pk_f16(x0, x1), h1 = pk_f16(x2, x3);
         const f32x2v w0 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h0), f32x2v);
         const f32x2v w1 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h1), f32x2v);
-        const unsigned m0 = pk_f16(x0 - w0.x, x1 - w0.y), m1 = pk_f16(x2 - w1.x, x3 - w1.y);
+        float r0 = x0 - w0.x, r1 = x1 - w0.y, r2 = x2 - w1.x, r3 = x3 - w1.y;
+        if constexpr (Ar<AR>::W2) { r0 *= H3_LOW; r1 *= H3_LOW; r2 *= H3_LOW; r3 *= H3_LOW; }
+        const unsigned m0 = pk_f16(r0, r1), m1 = pk_f16(r2, r3);
         q[0] = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
         q[1] = __builtin_bit_cast(bf16x4, u32x2v{m0, m1});
     } else {
@@ -84,12 +96,11 @@ __device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[Ar<AR>::NP
     }
 }
 
-// ---- h3 scales.  An operand with |x| <= bound is multiplied by 2^e, e = h3_exp(bound), so that |x| 2^e < 2^14 (fp16 holds
-// 65504: a factor 4 of headroom for the rounding of the bound itself).  Elements down to 2^-17 of the bound keep both pieces
-// normal (relative error 2^-24); smaller ones lose relative precision gracefully, absolute error <= 2^-39 of the bound.
+// ---- h3 scales.  An operand with |x| <= bound is multiplied by 2^e, e = h3_exp(bound), so that 2^14 <= bound 2^e < 2^15 (fp16
+// holds 65504: a factor 2 of headroom for the rounding of a computed bound).
 __device__ __forceinline__ int h3_exp(float bound) {          // bound >= 0 (NaN / inf: the scaled operand overflows to inf -> NaN)
     const int ex = (int)((__float_as_uint(bound) >> 23) & 0xffu);       // bound < 2^(ex - 126)
-    const int e = 140 - ex;
+    const int e = 141 - ex;
     return e > 100 ? 100 : (e < -100 ? -100 : e);
 }
 __device__ __forceinline__ float h3_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }   // |e| <= 126
@@ -98,14 +109,18 @@ __device__ __forceinline__ float h3_pro_bound(float amax, float alpha, float mea
     const float pa = fmaxf(1.f, fabsf(alpha)) * amax;
     return gbmax[0] * fabsf(rstd) * (pa + fabsf(mean)) + gbmax[1];
 }
-// acc *= 2^-(ea + eb): v_ldexp_f32 (exact; overflows / underflows only where the result itself does)
-template <int N>
-__device__ __forceinline__ void h3_unscale(f32x16 (&acc)[N], int ea, int eb) {
+// acc = (acc + 2^-11 acc2) 2^-(ea + eb): v_ldexp_f32 (exact; overflows / underflows only where the result itself does)
+template <bool W2, int N, int N2>
+__device__ __forceinline__ void h3_unscale(f32x16 (&acc)[N], const f32x16 (&acc2)[N2], int ea, int eb) {
     const int t = -(ea + eb);
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = __builtin_amdgcn_ldexpf(acc[i][e], t);
+        for (int e = 0; e < 16; ++e) {
+            float v = acc[i][e];
+            if constexpr (W2) v = fmaf(acc2[i][e], 1.f / H3_LOW, v);
+            acc[i][e] = __builtin_amdgcn_ldexpf(v, t);
+        }
 }
 
 // The piece products of one 16-deep step in issue order, smallest terms first: (piece of A, piece of B).
@@ -118,10 +133,16 @@ template <> struct Prods<3> {
     static constexpr int N = 6;
     static constexpr int A[N] = {2, 0, 1, 1, 0, 0}, B[N] = {0, 2, 1, 0, 1, 0};
 };
-// acc += sum over the piece products of a (NP fragments) and b (NP fragments)
+// acc += sum over the piece products of a (NP fragments) and b (NP fragments); W2: the cross products go to acc2
 template <int AR>
-__device__ __forceinline__ void mfma_pieces(f32x16& acc, const bf16x8 (&fa)[Ar<AR>::NP], const bf16x8 (&fb)[Ar<AR>::NP]) {
+__device__ __forceinline__ void mfma_pieces(f32x16& acc, f32x16& acc2, const bf16x8 (&fa)[Ar<AR>::NP], const bf16x8 (&fb)[Ar<AR>::NP]) {
     constexpr int NP = Ar<AR>::NP;
+    if constexpr (Ar<AR>::W2) {
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[1]), __builtin_bit_cast(f16x8, fb[0]), acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, fb[0]), acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[0]), __builtin_bit_cast(f16x8, fb[1]), acc2, 0, 0, 0);
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < Prods<NP>::N; ++t) {
         if constexpr (Ar<AR>::F16)
@@ -286,7 +307,7 @@ void pw_gemm_b3_kernel(PwArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j) mfma_pieces<AR>(acc[i][j], af[i], bfr[j]);      // small terms first
+                for (int j = 0; j < NTL; ++j) mfma_pieces<AR>(acc[i][j], acc[i][j], af[i], bfr[j]);      // small terms first
         }
     };
 
@@ -399,10 +420,11 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     };
 
     f32x16 acc[2];                  // rows wm * 64 + 32 i, columns wn * 32
+    f32x16 acc2[Ar<AR>::W2 ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int e = 0; e < 16; ++e) { acc[i][e] = 0.f; acc2[Ar<AR>::W2 ? i : 0][e] = 0.f; }
 
     const int l31 = lane & 31, lhi = lane >> 5;
     auto compute = [&](int stage) {
@@ -419,7 +441,7 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
                 bfr[p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + (wn * 32 + l31) * XPA + ks * 16 + lhi * 8);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) mfma_pieces<AR>(acc[i], af[i], bfr);
+            for (int i = 0; i < 2; ++i) mfma_pieces<AR>(acc[i], acc2[Ar<AR>::W2 ? i : 0], af[i], bfr);
         }
     };
     // Register ring of PF k-tiles: at the top of iteration kt, LDS stage kt % 2 holds tile kt, ring slots (kt + 1 .. kt + PF - 1)
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
             }
         }
     }
-    if constexpr (Ar<AR>::F16) h3_unscale<2>(acc, eg, ex);
+    if constexpr (Ar<AR>::F16) h3_unscale<Ar<AR>::W2>(acc, acc2, eg, ex);
     float* __restrict__ S = a.slab + (size_t)sp * a.R * a.Cn;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -500,7 +522,7 @@ __device__ unsigned long long ctn_dbg_tl[8192 * 12];
 #endif
 
 template <int AR, typename TL, int PRO, int EPI>
-__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? (Ar<AR>::NP == 2 ? 4 : 3) : 2)
+__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? ((Ar<AR>::NP == 2 && !Ar<AR>::W2) ? 4 : 3) : 2)
 void pw_gemm_b3p_kernel(PwArgs a) {
     constexpr int NP = Ar<AR>::NP;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, NTH = TL::NTH;
@@ -616,12 +638,13 @@ void pw_gemm_b3p_kernel(PwArgs a) {
     };
 
     f32x16 acc[MT][NTL];
+    f32x16 acc2[Ar<AR>::W2 ? MT : 1][Ar<AR>::W2 ? NTL : 1];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTL; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acc2[Ar<AR>::W2 ? i : 0][Ar<AR>::W2 ? j : 0][e] = 0.f; }
 
     auto compute = [&](int stage, const bf16x8 (&fa)[MT][2][NP]) {
         const __bf16* const S = Bp + stage * L::STAGE_ELEMS;
@@ -647,7 +670,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
                         acc[i][j][p] += x.x * y.x; acc[i][j][p + 4] += x.y * y.y; acc[i][j][p + 8] += x.z * y.z; acc[i][j][p + 12] += x.w * y.w;
                     }
 #else
-                    mfma_pieces<AR>(acc[i][j], fa[i][ks], bfr[j]);
+                    mfma_pieces<AR>(acc[i][j], acc2[Ar<AR>::W2 ? i : 0][Ar<AR>::W2 ? j : 0], fa[i][ks], bfr[j]);
 #endif
                 }
         }
@@ -682,7 +705,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
 #else
     if constexpr (Ar<AR>::F16) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) h3_unscale<NTL>(acc[i], ew, ex);
+        for (int i = 0; i < MT; ++i) h3_unscale<Ar<AR>::W2>(acc[i], acc2[Ar<AR>::W2 ? i : 0], ew, ex);
     }
     gemm_epilogue<TL, EPI>(a, acc, reinterpret_cast<float*>(smem_raw), red, m, rt, ct);
 #endif
@@ -834,7 +857,7 @@ static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, boo
         }
         return;
     }
-    if constexpr (AR != 4) {        // fp32 weights split on the fly: the bf16 arithmetics
+    if constexpr (AR < 4) {         // fp32 weights split on the fly: the bf16 arithmetics
         switch (tile) {
             case 1: launch_b3_tile<AR, T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
             case 2: launch_b3_tile<AR, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
@@ -848,7 +871,7 @@ static void ctn_b3_launch_fwd(int ar, PwArgs& a, int trans_w, bool pro, bool res
     const int tile = ctn_b3_pick_tile(a, trans_w, pro, residual, stats, gln_bwd);
     a.tiles_r = ctn_cdiv(a.R, d[tile][0]);
     a.tiles_c = ctn_cdiv(a.Kp, d[tile][1]);
-    if (ar == 4) ctn_b3_launch_fwd_np<4>(tile, a, 2, pro, residual, stats, relu, gln_bwd, st);       // (pre-split weights only)
+    if (ar == 4) ctn_b3_launch_fwd_np<H3AR>(tile, a, 2, pro, residual, stats, relu, gln_bwd, st);       // h3 (pre-split weights only)
     else if (ar == 3) ctn_b3_launch_fwd_np<3>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
     else ctn_b3_launch_fwd_np<2>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
 }
@@ -885,7 +908,7 @@ static void ctn_b3_launch_split(int ar, const void* const* src, void* const* dst
         sa.sr = k_major ? 1 : Cn; sa.sk = k_major ? R : 1;
         sa.nkt = (Cn + XK - 1) / XK * 2;
         const dim3 grid(ctn_cdiv(sa.nkt, 4), (R + 31) / 32, cnt);
-        if (ar == 4) hipLaunchKernelGGL(split_b3_kernel<4>, grid, dim3(256), 0, st, sa);
+        if (ar == 4) hipLaunchKernelGGL(split_b3_kernel<H3AR>, grid, dim3(256), 0, st, sa);
         else if (ar == 3) hipLaunchKernelGGL(split_b3_kernel<3>, grid, dim3(256), 0, st, sa);
         else hipLaunchKernelGGL(split_b3_kernel<2>, grid, dim3(256), 0, st, sa);
     }
@@ -915,7 +938,7 @@ static int ctn_b3_launch_wgrad(int ar, WgArgs& a, bool pro, hipStream_t st) {
     a.tiles_c = ctn_cdiv(a.Cn, BN);
     const int nsplit = a.M * a.chunks_per_m;
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit));
-    if (ar == 4) ctn_b3_launch_wgrad_np<4>(a, pro, grid, st);
+    if (ar == 4) ctn_b3_launch_wgrad_np<H3AR>(a, pro, grid, st);
     else if (ar == 3) ctn_b3_launch_wgrad_np<3>(a, pro, grid, st);
     else ctn_b3_launch_wgrad_np<2>(a, pro, grid, st);
     return nsplit;

@@ -779,11 +779,13 @@ template <int CPT>
 __global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restrict__ Y, float* __restrict__ Out,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                            int M, int Ch, int K, int Kp, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ alpha_p) {
+                                                           const float* __restrict__ beta, const float* __restrict__ alpha_p,
+                                                           unsigned* __restrict__ amax_out) {
     __shared__ float4 sh[C4_NT / 64][C4_FR / 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid & 7, g = tid >> 3;
     const int kb = Kp / C4_FR;
     const int m = blockIdx.x / kb, k0 = (blockIdx.x % kb) * C4_FR + 4 * q;
+    float amax = 0.f;
     const bool has_a = alpha_p != nullptr;
     const float al = has_a ? alpha_p[0] : 1.f;
     const size_t off = (size_t)m * Ch * Kp + k0;
@@ -825,9 +827,12 @@ __global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restri
             o.y = k0 + 1 < K ? ga * ((v[j].y - mu.y) * rs.y) + be : 0.f;
             o.z = k0 + 2 < K ? ga * ((v[j].z - mu.z) * rs.z) + be : 0.f;
             o.w = k0 + 3 < K ? ga * ((v[j].w - mu.w) * rs.w) + be : 0.f;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             *reinterpret_cast<float4*>(Out + off + (size_t)c * Kp) = o;
         }
     }
+    if (amax_out != nullptr)        // h3 arithmetic of the GEMM that reads Out: its maximum per utterance
+        block_amax_atomic<C4_NT>(amax, reinterpret_cast<double*>(&sh[0][0]), amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % kb);
 }
 
 // NTB threads = NTB/8 channel groups.  CPT = 8 at 512 threads needs 161 VGPRs (one workgroup = 2 waves per SIMD) and is
@@ -839,7 +844,8 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
                                                            const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
                                                            const float* __restrict__ gamma, const float* __restrict__ alpha_p,
                                                            const float* __restrict__ add, const float* __restrict__ relu_ref,
-                                                           float* __restrict__ dalpha_part, float* __restrict__ pc) {
+                                                           float* __restrict__ dalpha_part, float* __restrict__ pc,
+                                                           unsigned* __restrict__ amax_out) {
     constexpr int NW = NTB / 64, NG = NTB / (C4_FR / 4);
     __shared__ float4 sh[NW][C4_FR / 4];
     __shared__ float red[NW];
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
     const float inv = 1.f / (float)Ch;
     m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
     m2.x *= inv; m2.y *= inv; m2.z *= inv; m2.w *= inv;
-    float dal = 0.f;
+    float dal = 0.f, amax = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int c = g + NG * j;
@@ -911,6 +917,7 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
                 }
                 r[e] = x;
             }
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r[0]), fabsf(r[1]))), fmaxf(fabsf(r[2]), fabsf(r[3])));
             *reinterpret_cast<float4*>(dY + o) = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
@@ -918,6 +925,8 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
         dal = block_sum<float, NTB>(dal, red);
         if (tid == 0) dalpha_part[blockIdx.x] = dal;
     }
+    if (amax_out != nullptr)
+        block_amax_atomic<NTB>(amax, reinterpret_cast<double*>(&sh[0][0]), amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % kb);
 }
 
 // per-(m,c) partial of dgamma = sum_k dOut*xh and dbeta = sum_k dOut ; pc[2][rows][Ch], rows >= M (fallback of the v4 kernel)
@@ -1065,6 +1074,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_taps_kernel(const float* __restrict
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" int ctn_absmax_rows(const float* x, int M, long long n, unsigned* amax, void* stream);      // ctn_gemm.hip
 
 extern "C" {
 
@@ -1218,13 +1229,13 @@ static bool cln_v4_ok(int Ch, int Kp, const void* a, const void* b, const void* 
 }
 
 int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int Ch, int K, int Kp,
-                const float* gamma, const float* beta, const float* alpha, void* stream) {
+                const float* gamma, const float* beta, const float* alpha, unsigned* amax_out, void* stream) {
     CTN_REQUIRE(Y && Out && mean && rstd && gamma && beta, "ctn_cln_fwd: null pointer");
     CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K, "ctn_cln_fwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     if (cln_v4_ok(Ch, Kp, Y, Out, mean) && aligned16(rstd)) {     // 16-byte accesses along frames (round 2)
         const dim3 grid((unsigned)(M * (Kp / C4_FR)));
-#define CTN_CLN_FWD4(CPT_) hipLaunchKernelGGL((cln_fwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha)
+#define CTN_CLN_FWD4(CPT_) hipLaunchKernelGGL((cln_fwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha, amax_out)
         const int cpt = ctn_cdiv(Ch, C4_NG);
         if (cpt <= 1) CTN_CLN_FWD4(1);
         else if (cpt <= 2) CTN_CLN_FWD4(2);
@@ -1246,6 +1257,7 @@ int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int
                             gamma, beta, alpha);
 #undef CTN_CLN_FWD
     CTN_CHECK_LAUNCH("ctn_cln_fwd");
+    if (amax_out != nullptr) return ctn_absmax_rows(Out, M, (long long)Ch * Kp, amax_out, stream);     // fallback kernels: a pass of its own
     return CTN_OK;
 }
 
@@ -1255,7 +1267,7 @@ size_t ctn_cln_bwd_pc_floats(int M, int Ch, int Kp) { return (size_t)2 * ctn_cln
 // see include/ctn_hip.h.  pc is [2][ctn_cln_bwd_blocks(M, Kp)][Ch]
 int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
                 int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
-                const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream) {
+                const float* add, const float* relu_ref, float* dalpha_part, float* pc, unsigned* amax_out, void* stream) {
     CTN_REQUIRE(dOut && Y && dY && mean && rstd && gamma && pc, "ctn_cln_bwd: null pointer");
     CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_cln_bwd: bad sizes");
     CTN_REQUIRE(!alpha || dalpha_part, "ctn_cln_bwd: dalpha_part required with alpha");
@@ -1267,7 +1279,7 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
         // one pass: input gradient AND the parameter-gradient partials (dY may alias dOut: each thread reads its elements
         // of dOut before it writes them)
         const dim3 grid((unsigned)rows);
-#define CTN_CLN_BWD4(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, NTB_>), grid, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc)
+#define CTN_CLN_BWD4(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, NTB_>), grid, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out)
         if (Ch <= C4_NG) CTN_CLN_BWD4(1, C4_NT);
         else if (Ch <= 2 * C4_NG) CTN_CLN_BWD4(2, C4_NT);
         else if (Ch <= 4 * C4_NG) CTN_CLN_BWD4(4, C4_NT);
@@ -1295,6 +1307,7 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     }
 #undef CTN_CLN_BWD
     CTN_CHECK_LAUNCH("ctn_cln_bwd/dx");
+    if (amax_out != nullptr) return ctn_absmax_rows(dY, M, (long long)Ch * Kp, amax_out, stream);      // fallback kernels: a pass of its own
     return CTN_OK;
 }
 

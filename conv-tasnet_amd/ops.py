@@ -148,6 +148,11 @@ def _b3_planes_ok(R):
     return R >= 64 and lib.ctn_gemm_arith() != 0
 
 
+def _h3_block(B, H):
+    """The rule of the composite stacks (csrc/ctn_block.hip: use_h3): h3 arithmetic selected and both layer widths >= 64."""
+    return lib.ctn_gemm_arith() == 3 and B >= 64 and H >= 64
+
+
 def _b3_pieces(W, R, Cn, k_major):
     """bf16 piece fragments of one GEMM weight operand [R, Cn] (ctn_split_b3_batch); W stored [Cn, R] when k_major."""
     dst = torch.empty(lib.ctn_split_b3_bytes(R, Cn), dtype=torch.uint8, device=W.device)
@@ -215,12 +220,12 @@ def pw_dgrad_gln_h3(Wp, dOut, R, Cn, K, y, gamma, alpha, ms, g_amax):
     return dn, part
 
 
-def pw_wgrad_h3(dOut, X, R, Cn, K, g_amax, x_amax, pro=None, gbmax=None):
+def pw_wgrad_h3(dOut, X, R, Cn, K, g_amax, x_amax, pro=None, gbmax=None, out=None, ws_tag="wgrad_h3"):
     """ctn_pw_wgrad_h3: dW[R,Cn] = sum_{m,k} dOut[m,r,k] * f(X[m,c,k]).  pro = (gamma, beta, alpha, ms[M,2])."""
     M, _, Kp = X.shape
-    dW = torch.empty((R, Cn), dtype=F32, device=X.device)
+    dW = torch.empty((R, Cn), dtype=F32, device=X.device) if out is None else out
     nbytes = lib.ctn_pw_wgrad_h3_workspace(M, R, Cn, Kp)
-    ws = _workspace(nbytes, X.device, "wgrad_h3")
+    ws = _workspace(nbytes, X.device, ws_tag)
     pg, pb, pa, pms = (None, None, None, None) if pro is None else pro
     _chk(dOut, X, pg, pb, pa, pms, gbmax)
     _chk_aux(g_amax, x_amax)
@@ -285,8 +290,9 @@ def join_side_stream(device=None):
             _order(st, torch.cuda.current_stream(dev))
 
 
-def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=()):
+def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=(), h3=None):
     """pw_wgrad on the side stream, ordered after everything issued so far on the current stream.
+    h3 = (g_amax, x_amax, gbmax): the same through ctn_pw_wgrad_h3.
 
     first(): other gradient-finishing launches that ride behind the same cross-stream event (each event costs the
     issuing queue a bubble, so they never get one of their own); first_inputs: the tensors they read."""
@@ -296,8 +302,11 @@ def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=()):
     with torch.cuda.stream(side):
         if first is not None:
             first()
-        pw_wgrad(dOut, X, R, Cn, K, pro=pro, out=out, ws_tag="wgrad_side")
-    for t in (dOut, X) + (tuple(pro) if pro is not None else ()) + tuple(first_inputs):
+        if h3 is not None:
+            pw_wgrad_h3(dOut, X, R, Cn, K, h3[0], h3[1], pro=pro, gbmax=h3[2], out=out, ws_tag="wgrad_side")
+        else:
+            pw_wgrad(dOut, X, R, Cn, K, pro=pro, out=out, ws_tag="wgrad_side")
+    for t in (dOut, X) + (tuple(pro) if pro is not None else ()) + tuple(first_inputs) + tuple(t for t in (h3 or ()) if t is not None):
         t.record_stream(side)        # the caching allocator must not hand these out before the side stream is done
 
 
@@ -338,7 +347,7 @@ def cln_fwd(Y, gamma, beta, alpha, K):
     mean = torch.empty((M, Kp), dtype=F32, device=Y.device)
     rstd = torch.empty((M, Kp), dtype=F32, device=Y.device)
     _chk(Y, gamma, beta, alpha)
-    lib.call("ctn_cln_fwd", _p(Y), _p(out), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(beta), _p(alpha), _stream())
+    lib.call("ctn_cln_fwd", _p(Y), _p(out), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(beta), _p(alpha), 0, _stream())
     return out, mean, rstd
 
 
@@ -353,7 +362,7 @@ def cln_bwd(dOut, Y, mean, rstd, gamma, alpha, K, add=None, relu_ref=None, sinks
         dap = torch.empty((lib.ctn_cln_bwd_blocks(M, Kp),), dtype=F32, device=Y.device)
     _chk(dOut, Y, mean, rstd, gamma, alpha, add, relu_ref)
     lib.call("ctn_cln_bwd", _p(dOut), _p(Y), _p(dY), _p(mean), _p(rstd), M, Ch, K, Kp, _p(gamma), _p(alpha),
-             _p(add), _p(relu_ref), _p(dap), _p(pc), _stream())
+             _p(add), _p(relu_ref), _p(dap), _p(pc), 0, _stream())
     if sinks is not None:
         dg, db, da = sinks
     else:
@@ -456,11 +465,22 @@ class GlnBlock(torch.autograd.Function):
         if H % 4 or B % 4:
             raise ValueError("HIP path needs B and H to be multiples of 4")
         dev = x.device
-        h1, st1 = pw_gemm(w1, x, H, B, K, epi_alpha=a1)
         ms1 = torch.empty((M, 2), dtype=F32, device=dev)
-        d, st2 = dw_fwd(h1, D, K, dilation, causal, pro=(st1, g1, b1, a1), epi_alpha=a2, ms_out=ms1)
         ms2 = torch.empty((M, 2), dtype=F32, device=dev)
-        out, _ = pw_gemm(w2, d, B, H, K, pro=(st2, g2, b2, a2), residual=x, ms_out=ms2)
+        h3 = _h3_block(B, H)
+        if h3:      # the composite stack's arithmetic, kernel by kernel: the tracked maxima are exact, so measuring them here
+            #         (absmax_rows) gives the scales -- and the bits -- of the composite, whose producers track them on the fly
+            ax = absmax_rows(x)
+            h1, st1 = pw_gemm_h3(h3_pieces(w1, H, B, False), x, H, B, K, ax, epi_alpha=a1)
+            d, st2 = dw_fwd(h1, D, K, dilation, causal, pro=(st1, g1, b1, a1), epi_alpha=a2, ms_out=ms1)
+            ad = absmax_rows(d)
+            out, _ = pw_gemm_h3(h3_pieces(w2, B, H, False), d, B, H, K, ad, pro=(st2, g2, b2, a2), gbmax=absmax_of(g2, b2), residual=x, ms_out=ms2)
+            ctx.h3 = (ax, ad)
+        else:
+            h1, st1 = pw_gemm(w1, x, H, B, K, epi_alpha=a1)
+            d, st2 = dw_fwd(h1, D, K, dilation, causal, pro=(st1, g1, b1, a1), epi_alpha=a2, ms_out=ms1)
+            out, _ = pw_gemm(w2, d, B, H, K, pro=(st2, g2, b2, a2), residual=x, ms_out=ms2)
+            ctx.h3 = None
         ctx.save_for_backward(x, h1, d, ms1, ms2, w1, a1, g1, b1, D, a2, g2, b2, w2)
         ctx.cfg = (K, dilation, causal)
         ctx.sinks = tuple(_sink(p) for p in (w1, a1, g1, b1, D, a2, g2, b2, w2))
@@ -482,12 +502,20 @@ class GlnBlock(torch.autograd.Function):
         st = _stream()
         # -- second 1x1: input gradient (+ gLN2 backward sums) and weight gradient
         _chk(dout, x, h1, d)
-        dn2, s2p = pw_dgrad_gln(w2, dout, H, B, K, d, g2, a2, ms2)
+        h3 = ctx.h3
+        if h3 is not None:
+            ax, ad = h3
+            ady, gbm = absmax_rows(dout), absmax_of(g2, b2)
+            dn2, s2p = pw_dgrad_gln_h3(h3_pieces(w2, H, B, True), dout, H, B, K, d, g2, a2, ms2, ady)
+        else:
+            dn2, s2p = pw_dgrad_gln(w2, dout, H, B, K, d, g2, a2, ms2)
         np2 = s2p.shape[1]
         side = direct and _SIDE_ENABLED
         if side:
-            _wgrad_async(dout, d, B, H, K, sinks[8], pro=(g2, b2, a2, ms2))
+            _wgrad_async(dout, d, B, H, K, sinks[8], pro=(g2, b2, a2, ms2), h3=None if h3 is None else (ady, ad, gbm))
             dW2 = None
+        elif h3 is not None:
+            dW2 = pw_wgrad_h3(dout, d, B, H, K, ady, ad, pro=(g2, b2, a2, ms2), gbmax=gbm, out=sinks[8] if direct else None)
         else:
             dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2), out=sinks[8] if direct else None)
         # -- gLN2 <- PReLU2 <- depthwise <- gLN1 output, one pass
@@ -519,14 +547,21 @@ class GlnBlock(torch.autograd.Function):
         if not side_fin:
             finish()
         # -- first 1x1
+        h3w = None if h3 is None else (absmax_rows(dn1), ax, None)
         if side:
             if side_fin:
-                _wgrad_async(dn1, x, H, B, K, sinks[0], first=finish, first_inputs=(pc, da1p))
+                _wgrad_async(dn1, x, H, B, K, sinks[0], first=finish, first_inputs=(pc, da1p), h3=h3w)
             else:
-                _wgrad_async(dn1, x, H, B, K, sinks[0])
-        dx, _ = pw_gemm(w1, dn1, B, H, K, trans_w=True, residual=dout)
+                _wgrad_async(dn1, x, H, B, K, sinks[0], h3=h3w)
+        if h3 is not None:
+            dx, _ = pw_gemm_h3(h3_pieces(w1, B, H, True), dn1, B, H, K, h3w[0], residual=dout)
+        else:
+            dx, _ = pw_gemm(w1, dn1, B, H, K, trans_w=True, residual=dout)
         if not side:
-            dW1 = pw_wgrad(dn1, x, H, B, K, out=sinks[0] if direct else None)
+            if h3 is not None:
+                dW1 = pw_wgrad_h3(dn1, x, H, B, K, h3w[0], ax, out=sinks[0] if direct else None)
+            else:
+                dW1 = pw_wgrad(dn1, x, H, B, K, out=sinks[0] if direct else None)
         if direct:
             return (dx,) + (None,) * 12
         return (dx, dW1.view(H, B, 1), da1, dg1, db1, dD, da2, dg2, db2, dW2.view(B, H, 1), None, None, None)
@@ -688,10 +723,11 @@ def tcn_cln_infer(x0, K, dilations, causal, params):
     xs = torch.empty((2, M, B, Kp), dtype=F32, device=dev)
     h = torch.empty((4, M, H, Kp), dtype=F32, device=dev)
     st = torch.empty((4, M, Kp), dtype=F32, device=dev)
+    amax = torch.empty((nb, 2, M, AMAX_SLOTS), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked operand maxima (zeroed by the call)
     nbytes = lib.ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nb)
     ws = _workspace(nbytes, dev, "tcn_cln_fwd")
     dil = (ctypes.c_int * nb)(*dilations)
-    lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h[0]), _p(h[1]), _p(h[2]), _p(h[3]), _p(st), 0,
+    lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(h[0]), _p(h[1]), _p(h[2]), _p(h[3]), _p(st), _p(amax), 0,
              M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
     return xs[(nb - 1) & 1]
 
@@ -715,12 +751,13 @@ class TcnCln(torch.autograd.Function):
         xs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
         hs = torch.empty((4, nb, M, H, Kp), dtype=F32, device=dev)          # h1, n1, d, n2
         st = torch.empty((nb, 4, M, Kp), dtype=F32, device=dev)            # mean1, rstd1, mean2, rstd2
+        amax = torch.empty((nb, 2, M, AMAX_SLOTS), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked maxima of every block's input / second norm output
         nbytes = lib.ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nb)
         ws = _workspace(nbytes, dev, "tcn_cln_fwd")
         dil = (ctypes.c_int * nb)(*dilations)
-        lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]), _p(hs[3]), _p(st), 1,
+        lib.call("ctn_tcn_cln_fwd", _ptr_table(params), dil, nb, _p(x0), _p(xs), _p(hs[0]), _p(hs[1]), _p(hs[2]), _p(hs[3]), _p(st), _p(amax), 1,
                  M, B, H, K, Kp, P, int(causal), _p(ws), nbytes, _stream(), _fwd_side(dev))
-        ctx.acts = (x0, xs, hs, st)
+        ctx.acts = (x0, xs, hs, st, amax)
         ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
         ctx.cfg = (K, dil, nb, causal, P)
         ctx.sinks = tuple(_sink(p) for p in params)
@@ -731,7 +768,7 @@ class TcnCln(torch.autograd.Function):
         if ctx.acts is None:
             raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
                            "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
-        x0, xs, hs, st = ctx.acts
+        x0, xs, hs, st, amax = ctx.acts
         params = ctx.saved_tensors
         K, dil, nb, causal, P = ctx.cfg
         dout = _c(dout)
@@ -762,7 +799,7 @@ class TcnCln(torch.autograd.Function):
             wsi = _workspace(nbi, dev, "tcn_cln_bwd_bucket%d" % i) if unjoined else ws
             lib.call("ctn_tcn_cln_bwd", _ptr_table(params[lo * NPARAM:hi * NPARAM]), _ptr_table(gdst[lo * NPARAM:hi * NPARAM]),
                      (ctypes.c_int * (hi - lo))(*dil[lo:hi]), hi - lo, _p(x0 if lo == 0 else xs[lo - 1]), _p(xs[lo]), _p(hs[0][lo]),
-                     _p(hs[1][lo]), _p(hs[2][lo]), _p(hs[3][lo]), _p(st[lo]), _p(dout if hi == nb else dxs[hi]), _p(dxs[lo]), _p(dh1s[lo]),
+                     _p(hs[1][lo]), _p(hs[2][lo]), _p(hs[3][lo]), _p(st[lo]), _p(amax[lo]), _p(dout if hi == nb else dxs[hi]), _p(dxs[lo]), _p(dh1s[lo]),
                      M, B, H, K, Kp, P, int(causal), _p(wsi), nbi, _stream(), 0 if side is None else side.cuda_stream, int(unjoined))
             if gb is not None:
                 with torch.cuda.stream(side if side is not None else torch.cuda.current_stream(dev)):
@@ -784,11 +821,21 @@ class ClnBlock(torch.autograd.Function):
         H = w1.shape[0]
         if H % 4 or B % 4:
             raise ValueError("HIP path needs B and H to be multiples of 4")
-        h1, _ = pw_gemm(w1, x, H, B, K)
+        h3 = _h3_block(B, H)       # the composite stack's arithmetic, kernel by kernel (maxima measured here: exact, so the same bits)
+        if h3:
+            ax = absmax_rows(x)
+            h1, _ = pw_gemm_h3(h3_pieces(w1, H, B, False), x, H, B, K, ax)
+        else:
+            h1, _ = pw_gemm(w1, x, H, B, K)
         n1, mean1, rstd1 = cln_fwd(h1, g1, b1, a1, K)
         d, _ = dw_fwd(n1, D, K, dilation, causal)
         n2, mean2, rstd2 = cln_fwd(d, g2, b2, a2, K)
-        out, _ = pw_gemm(w2, n2, B, H, K, residual=x)
+        if h3:
+            an = absmax_rows(n2)
+            out, _ = pw_gemm_h3(h3_pieces(w2, B, H, False), n2, B, H, K, an, residual=x)
+        else:
+            out, _ = pw_gemm(w2, n2, B, H, K, residual=x)
+        ctx.h3 = (ax, an) if h3 else None
         ctx.save_for_backward(x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2)
         ctx.cfg = (K, dilation, causal)
         ctx.sinks = tuple(_sink(p) for p in (w1, a1, g1, b1, D, a2, g2, b2, w2))
@@ -811,10 +858,18 @@ class ClnBlock(torch.autograd.Function):
         # 1024-thread cLN kernels fill every wave slot); with the w4 kernel and the 5 us slab reduce it wins, 20.07 vs
         # 21.7 ms/step at paper size (CONFIG=causal benchmarks/ab_step.py).  CTN_CLN_SIDE=0 turns it off.
         side = direct and _SIDE_ENABLED and _CLN_SIDE
-        dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
+        h3 = ctx.h3
+        if h3 is not None:
+            ax, an = h3
+            ady = absmax_rows(dout)
+            dn2, _ = pw_gemm_h3(h3_pieces(w2, H, B, True), dout, H, B, K, ady)
+        else:
+            dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
         if side:
-            _wgrad_async(dout, n2, B, H, K, sk[8])
+            _wgrad_async(dout, n2, B, H, K, sk[8], h3=None if h3 is None else (ady, an, None))
             dW2 = None
+        elif h3 is not None:
+            dW2 = pw_wgrad_h3(dout, n2, B, H, K, ady, an, out=sk[8] if direct else None)
         else:
             dW2 = pw_wgrad(dout, n2, B, H, K, out=sk[8] if direct else None)
         dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K, sinks=(sk[6], sk[7], sk[5]) if direct else None)
@@ -825,12 +880,19 @@ class ClnBlock(torch.autograd.Function):
                  0, 0, 0, 0, 0, 0, 0, 0, 0, _p(pc), 0, _stream())
         dD = reduce_mid(pc, P, M, H).t().contiguous().view(H, 1, P)
         dh1, dg1, db1, da1 = cln_bwd(dn1, h1, mean1, rstd1, g1, a1, K, sinks=(sk[2], sk[3], sk[1]) if direct else None)
+        adh = None if h3 is None else absmax_rows(dh1)
         if side:
-            _wgrad_async(dh1, x, H, B, K, sk[0])
+            _wgrad_async(dh1, x, H, B, K, sk[0], h3=None if h3 is None else (adh, ax, None))
             dW1 = None
-        dx, _ = pw_gemm(w1, dh1, B, H, K, trans_w=True, residual=dout)
+        if h3 is not None:
+            dx, _ = pw_gemm_h3(h3_pieces(w1, B, H, True), dh1, B, H, K, adh, residual=dout)
+        else:
+            dx, _ = pw_gemm(w1, dh1, B, H, K, trans_w=True, residual=dout)
         if not side:
-            dW1 = pw_wgrad(dh1, x, H, B, K, out=sk[0] if direct else None)
+            if h3 is not None:
+                dW1 = pw_wgrad_h3(dh1, x, H, B, K, adh, ax, out=sk[0] if direct else None)
+            else:
+                dW1 = pw_wgrad(dh1, x, H, B, K, out=sk[0] if direct else None)
         if direct:
             sk[4].copy_(dD)
             return (dx,) + (None,) * 12

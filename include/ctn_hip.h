@@ -254,30 +254,33 @@ int ctn_probe_read(int* fam, float* us, int cap);
  * forward  1x1 -> cLN(PReLU) -> depthwise -> cLN(PReLU) -> 1x1 + residual,  backward the adjoint chain with the two weight
  * gradients on side_stream.  Saved by forward (slot per block): xs [nblocks][M,B,Kp]; h1s, n1s, ds, n2s [nblocks][M,H,Kp]
  * (1x1 output, first norm output, depthwise output, second norm output); st [nblocks][4][M,Kp] = mean1, rstd1, mean2, rstd2.
- * save = 0: two x slots, one slot of everything else.  backward scratch: dxs [nblocks][M,B,Kp], dh1s [nblocks][M,H,Kp]. */
+ * amax [nblocks][2][M][CTN_AMAX_SLOTS] (h3 arithmetic; may be NULL otherwise): tracked maxima of every block's input and of its
+ * second norm's output, written by forward, read by backward.
+ * save = 0: two x slots, one slot of everything else (amax all nblocks).  backward scratch: dxs [nblocks][M,B,Kp], dh1s [nblocks][M,H,Kp]. */
 int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks, const float* x0,
-                    float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, int save,
+                    float* xs, float* h1s, float* n1s, float* ds, float* n2s, float* st, unsigned* amax, int save,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream);
 size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks);
 int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* dilation, int nblocks,
                     const float* x0, const float* xs, const float* h1s, const float* n1s, const float* ds, const float* n2s,
-                    const float* st, const float* dout, float* dxs, float* dh1s,
+                    const float* st, const unsigned* amax, const float* dout, float* dxs, float* dh1s,
                     int M, int B, int H, int K, int Kp, int P, int causal,
                     void* workspace, size_t workspace_bytes, void* stream, void* side_stream, int flags);
 size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks);
 
 /* ---- channel-wise LayerNorm, src/conv_tasnet.py:313-335 (per frame, biased variance) -----
  * Out = gamma*((a-mean_k)*rstd_k)+beta with a = prelu(Y,alpha) if alpha != NULL else Y.
- * mean, rstd: [M,Kp] saved for backward. */
+ * mean, rstd: [M,Kp] saved for backward.  amax_out != NULL: [M][CTN_AMAX_SLOTS], receives max |Out[m]| (h3 section). */
 int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int Ch, int K, int Kp,
-                const float* gamma, const float* beta, const float* alpha, void* stream);
+                const float* gamma, const float* beta, const float* alpha, unsigned* amax_out, void* stream);
 /* dY = [cLN/PReLU backward of dOut  (+ add)] masked by (relu_ref > 0) when relu_ref != NULL -- and, in the same pass, the
  * parameter-gradient partials: pc [2][ctn_cln_bwd_blocks(M,Kp)][Ch] (ctn_cln_bwd_pc_floats() floats: dgamma, dbeta of every
- * 32-frame workgroup) and dalpha_part [ctn_cln_bwd_blocks(M,Kp)]; ctn_cln_bwd_finalize sums them in fixed order. */
+ * 32-frame workgroup) and dalpha_part [ctn_cln_bwd_blocks(M,Kp)]; ctn_cln_bwd_finalize sums them in fixed order.
+ * amax_out != NULL: [M][CTN_AMAX_SLOTS], receives max |dY[m]| (h3 section). */
 int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
                 int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
-                const float* add, const float* relu_ref, float* dalpha_part, float* pc, void* stream);
+                const float* add, const float* relu_ref, float* dalpha_part, float* pc, unsigned* amax_out, void* stream);
 int ctn_cln_bwd_blocks(int M, int Kp);
 size_t ctn_cln_bwd_pc_floats(int M, int Ch, int Kp);
 /* One launch that finishes the partials above in fixed order: dgamma[Ch], dbeta[Ch] from pc, and dalpha[1] from

@@ -1,0 +1,274 @@
+"""GPU: the "h3" GEMM arithmetic of the composite stacks (include/ctn_hip.h, "h3" section; csrc/ctn_gemm_b3.h) through its own
+entry points -- two fp16 pieces per fp32 operand under power-of-two scales derived from TRACKED maxima, three f16 MFMAs.
+
+What is asserted, with the limits of the fp32 arithmetic (nothing is widened for h3):
+  * every GEMM form (K1 statistics, K3 prologue + residual, B1 gLN-backward sums, B5 residual, both weight gradients) against
+    fp64 on unit-scale data AND on operands whose magnitudes the 5-bit exponent of fp16 could not hold unscaled: gradient-like
+    1e-20, large 1e6, utterances 2^-40 .. 2^40 apart, heavy tails -- error <= 6e-7 of sum |a||b| (the limit tests/test_gpu_b3.py
+    applies to the default arithmetic) or, where the fp32 MFMA itself is above that (heavy tails), <= 1.25x the fp32 MFMA's error
+    on the same data.  Observed on the MI355X (benchmarks/h3_check.py): 2.4e-7 against 3.9e-7 (b6) and 3.8e-7 (fp32 MFMA);
+  * the tracked maxima are EXACT (ctn_absmax_rows, residual epilogue, ctn_dw_fwd, ctn_gln_prelu_bwd, weight maxima), so the
+    per-kernel path that measures them and the composite that tracks them agree bit for bit (tests/test_gpu_train.py);
+  * edge cases: an all-zero utterance, NaN / inf confined to their utterance, elements far below their utterance's maximum
+    (absolute error <= 2^-38 of the maximum: graceful, documented loss of RELATIVE precision);
+  * at the paper config: the gradients of one training step against the fp64 CPU oracle -- h3's error is not above the fp32
+    MFMA's (observed 4.6e-6 against 1.5e-5 and 1.8e-5 for b6, benchmarks/arith_grad_err.py) -- and a 10-step trajectory: h3 stays
+    as close to the fp32-MFMA run as b6 does.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import DEFAULT_ARITH
+from oracle import ctn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+import conv_tasnet_amd as ctn  # noqa: E402
+from conv_tasnet_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def pad(t, Kp):
+    out = t.new_zeros(t.shape[:-1] + (Kp,))
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+def dot_err(got, ref, scale):
+    return float(((got.double().cpu() - ref).abs() / scale.clamp_min(1e-300)).max())
+
+
+def amax_f(slots):
+    """[M, 64] int32 bit patterns -> [M] float maxima"""
+    return slots.view(torch.float32).amax(1)
+
+
+SCENARIOS = {
+    # name: (activation magnitude, gradient magnitude, weight magnitude, heavy tails, per-utterance factors)
+    "unit": (1.0, 1.0, 0.05, False, None),
+    "training": (3.0, 1e-7, 0.05, False, None),
+    "tiny": (1.0, 1e-20, 1e-3, False, None),
+    "large": (1e6, 1e5, 30.0, False, None),
+    "heavy": (1.0, 1e-6, 0.05, True, None),
+    "per_m": (1.0, 1e-3, 0.05, False, (-40, 12, 40)),
+}
+
+
+@pytest.mark.parametrize("scenario", sorted(SCENARIOS))
+@pytest.mark.parametrize("M,B,H,K", [(3, 256, 512, 515), (3, 72, 132, 257)])
+def test_h3_gemm_forms_against_fp64(scenario, M, B, H, K):
+    sx, sg, sw, heavy, per_m = SCENARIOS[scenario]
+    Kp = ops.padded_frames(K)
+    xB, xH = torch.randn(M, B, K, generator=g(1)) * sx, torch.randn(M, H, K, generator=g(2)) * sx
+    gB, gH = torch.randn(M, B, K, generator=g(3)) * sg, torch.randn(M, H, K, generator=g(4)) * sg
+    if heavy:
+        for i, t in enumerate((xB, xH, gB, gH)):
+            t.mul_(torch.where(torch.rand(t.shape, generator=g(10 + i)) < 1e-4, 1e4, 1.0))
+    if per_m is not None:
+        f = torch.tensor([2.0 ** e for e in per_m]).view(M, 1, 1)
+        xB, xH, gB, gH = xB * f, xH * f, gB * f.flip(0), gH * f.flip(0)
+    xB, xH, gB, gH = (pad(t, Kp).to(DEV) for t in (xB, xH, gB, gH))
+    w1 = (torch.randn(H, B, generator=g(5)) * sw).to(DEV)
+    w2 = (torch.randn(B, H, generator=g(6)) * sw).to(DEV)
+    a = torch.full((1,), 0.25, device=DEV)
+    gam, bet = torch.randn(1, H, 1, generator=g(7)).to(DEV), torch.randn(1, H, 1, generator=g(8)).to(DEV)
+    p1, p2 = ops.h3_pieces(w1, H, B, False), ops.h3_pieces(w2, B, H, False)
+    q2, q1 = ops.h3_pieces(w2, H, B, True), ops.h3_pieces(w1, B, H, True)
+    axB, axH, agB, agH = (ops.absmax_rows(t) for t in (xB, xH, gB, gH))
+    gbm = ops.absmax_of(gam, bet)
+    assert torch.equal(gbm.cpu(), torch.stack([gam.abs().max(), bet.abs().max()]).cpu())
+    for t, am in ((xB, axB), (gH, agH)):
+        assert torch.equal(amax_f(am).cpu(), t.abs().amax((1, 2)).cpu())                   # exact
+    d = lambda t: t.double().cpu()  # noqa: E731
+
+    def check(got, fp32_fn, ref, scale):
+        e = dot_err(got, ref, scale)
+        if e >= 6e-7:                       # only where the fp32 MFMA itself is above the limit on this data
+            with ctn.gemm_arithmetic("fp32"):
+                e32 = dot_err(fp32_fn(), ref, scale)
+            assert e <= 1.25 * e32, (e, e32)
+
+    # K1: h1 = W1 x, statistics of prelu(h1)
+    ref = torch.einsum("rc,mck->mrk", d(w1), d(xB))
+    sc = torch.einsum("rc,mck->mrk", d(w1).abs(), d(xB).abs())
+    out, part = ops.pw_gemm_h3(p1, xB, H, B, K, axB, epi_alpha=a)
+    check(out, lambda: ops.pw_gemm(w1, xB, H, B, K)[0], ref, sc)
+    assert float(out[..., K:].abs().max()) == 0.0
+    pre = torch.where(ref >= 0, ref, 0.25 * ref)[..., :K]
+    s = part.sum(1).cpu()
+    assert torch.allclose(s[:, 0], pre.sum((1, 2)), rtol=1e-5, atol=1e-5 * float(pre.abs().sum((1, 2)).max()))
+    assert torch.allclose(s[:, 1], (pre ** 2).sum((1, 2)), rtol=1e-5)
+    # B5: dx = W1^T dh1 + dy, maximum of the result tracked by the epilogue
+    ref5 = torch.einsum("cr,mck->mrk", d(w1), d(gH)) + d(gB)
+    sc5 = torch.einsum("cr,mck->mrk", d(w1).abs(), d(gH).abs()) + d(gB).abs()
+    oam = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    out5, _ = ops.pw_gemm_h3(q1, gH, B, H, K, agH, residual=gB, out_amax=oam)
+    check(out5, lambda: ops.pw_gemm(w1, gH, B, H, K, trans_w=True, residual=gB)[0], ref5, sc5)
+    assert torch.equal(amax_f(oam), out5.abs().amax((1, 2)))                               # exact: the maximum of what was stored
+    # B1: dn2 = W2^T dy with the gLN-backward sums
+    prx = torch.where(xH >= 0, xH, 0.25 * xH).double()
+    cnt = H * K
+    mean = prx[..., :K].sum((1, 2)) / cnt
+    var = (prx[..., :K] ** 2).sum((1, 2)) / cnt - mean * mean
+    rstd = 1.0 / torch.sqrt(var + 1e-8)
+    ms = torch.stack([mean, rstd], -1).float().contiguous()
+    refb1 = torch.einsum("cr,mck->mrk", d(w2), d(gB))
+    scb1 = torch.einsum("cr,mck->mrk", d(w2).abs(), d(gB).abs())
+    dn2, bpart = ops.pw_dgrad_gln_h3(q2, gB, H, B, K, xH, gam, a, ms, agB)
+    check(dn2, lambda: ops.pw_dgrad_gln(w2, gB, H, B, K, xH, gam, a, ms)[0], refb1, scb1)
+    xhat = ((prx - mean[:, None, None]) * rstd[:, None, None]).cpu()
+    gd = d(gam) * refb1
+    S = bpart.sum(1).cpu()
+    for got, want, mag in ((S[:, 0], gd[..., :K].sum((1, 2)), gd[..., :K].abs().sum((1, 2))),
+                           (S[:, 1], (gd * xhat)[..., :K].sum((1, 2)), (gd * xhat)[..., :K].abs().sum((1, 2)))):
+        assert float(((got - want).abs() / mag.clamp_min(1e-300)).max()) < 1e-5
+    # K3: out = W2 gLN(prelu(d)) + x
+    st2 = torch.stack([prx[..., :K].sum((1, 2)), (prx[..., :K] ** 2).sum((1, 2))], -1).reshape(M, 1, 2).contiguous()
+    nrm = d(gam) * xhat + d(bet)
+    nrm[..., K:] = 0
+    ref3 = torch.einsum("rc,mck->mrk", d(w2), nrm) + d(xB)
+    sc3 = torch.einsum("rc,mck->mrk", d(w2).abs(), nrm.abs()) + d(xB).abs()
+    ms_out = torch.empty(M, 2, device=DEV)
+    out3, _ = ops.pw_gemm_h3(p2, xH, B, H, K, axH, pro=(st2, gam, bet, a), gbmax=gbm, residual=xB, ms_out=ms_out)
+    check(out3, lambda: ops.pw_gemm(w2, xH, B, H, K, pro=(st2, gam, bet, a), residual=xB)[0], ref3, sc3)
+    assert torch.allclose(ms_out.cpu(), ms.cpu(), rtol=2e-6)
+    # weight gradients
+    refw = torch.einsum("mrk,mck->rc", d(gH), d(xB))
+    scw = torch.einsum("mrk,mck->rc", d(gH).abs(), d(xB).abs())
+    check(ops.pw_wgrad_h3(gH, xB, H, B, K, agH, axB), lambda: ops.pw_wgrad(gH, xB, H, B, K), refw, scw)
+    refw2 = torch.einsum("mrk,mck->rc", d(gB), nrm)
+    scw2 = torch.einsum("mrk,mck->rc", d(gB).abs(), nrm.abs())
+    check(ops.pw_wgrad_h3(gB, xH, B, H, K, agB, axH, pro=(gam, bet, a, ms), gbmax=gbm),
+          lambda: ops.pw_wgrad(gB, xH, B, H, K, pro=(gam, bet, a, ms)), refw2, scw2)
+
+
+def test_h3_producers_track_exact_maxima():
+    """ctn_dw_fwd (statistics epilogue) and ctn_gln_prelu_bwd write the maximum of what they store, per utterance."""
+    M, H, K = 3, 132, 700
+    Kp = ops.padded_frames(K)
+    y = pad(torch.randn(M, H, K, generator=g(1)) * torch.tensor([1e-6, 1.0, 3e4]).view(M, 1, 1), Kp).to(DEV)
+    D = torch.randn(H, 1, 3, generator=g(2)).to(DEV)
+    a = torch.full((1,), 0.25, device=DEV)
+    gam, bet = torch.randn(1, H, 1, generator=g(3)).to(DEV), torch.randn(1, H, 1, generator=g(4)).to(DEV)
+    pre = torch.where(y >= 0, y, 0.25 * y).double()
+    st = torch.stack([pre[..., :K].sum((1, 2)), (pre[..., :K] ** 2).sum((1, 2))], -1).reshape(M, 1, 2).contiguous()
+    for dil in (1, 4, 64):
+        Z = torch.empty_like(y)
+        ep = torch.empty((M, H, 2), dtype=torch.float64, device=DEV)
+        am = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+        ctn.lib.call("ctn_dw_fwd", y.data_ptr(), Z.data_ptr(), D.data_ptr(), M, H, K, Kp, 3, dil, 0, st.data_ptr(), 1, gam.data_ptr(),
+                     bet.data_ptr(), a.data_ptr(), 0, a.data_ptr(), ep.data_ptr(), am.data_ptr(), ops._stream())
+        assert torch.equal(amax_f(am), Z.abs().amax((1, 2)))
+    dn = pad(torch.randn(M, H, K, generator=g(5)) * torch.tensor([1e-12, 1.0, 1e3]).view(M, 1, 1), Kp).to(DEV)
+    ms = torch.tensor([[0.1, 1.3]] * M, device=DEV)
+    s1p = torch.randn(M, H, 2, generator=g(6), dtype=torch.float64).to(DEV) * 1e-3
+    dY, dap = torch.empty_like(dn), torch.empty(M * H, device=DEV)
+    am = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+    ctn.lib.call("ctn_gln_prelu_bwd", dn.data_ptr(), y.data_ptr(), dY.data_ptr(), M, H, K, Kp, gam.data_ptr(), a.data_ptr(), ms.data_ptr(),
+                 s1p.data_ptr(), H, dap.data_ptr(), am.data_ptr(), ops._stream())
+    assert torch.equal(amax_f(am), dY.abs().amax((1, 2)))
+
+
+def test_h3_edge_cases():
+    """An all-zero utterance (no maximum to scale by), NaN / inf confined to their own utterance, and elements far below their
+    utterance's maximum: absolute error <= 2^-38 of max |x_m| times the row sum of |w| (the documented graceful loss)."""
+    M, B, H, K = 4, 64, 128, 300
+    Kp = ops.padded_frames(K)
+    x = pad(torch.randn(M, B, K, generator=g(1)), Kp)
+    x[1] = 0.0
+    x[2, 3, 7] = float("nan")
+    x[3, 5, 9] = float("inf")
+    x = x.to(DEV)
+    w = (torch.randn(H, B, generator=g(2)) * 0.1).to(DEV)
+    out, _ = ops.pw_gemm_h3(ops.h3_pieces(w, H, B, False), x, H, B, K, ops.absmax_rows(x))
+    ref = torch.einsum("rc,mck->mrk", w.double().cpu(), x.double().cpu())
+    sc = torch.einsum("rc,mck->mrk", w.double().cpu().abs(), x.double().cpu().abs())
+    assert dot_err(out[0], ref[0], sc[0]) < 6e-7
+    assert float(out[1].abs().max()) == 0.0
+    assert not torch.isfinite(out[2]).all() and not torch.isfinite(out[3]).all()          # poisoned utterances stay poisoned ...
+    assert torch.isfinite(out[0]).all()                                                   # ... and alone
+    # one huge element per utterance, everything else 2^-30 below it
+    y = pad(torch.randn(M, B, K, generator=g(3)) * 2.0 ** -30, Kp)
+    y[:, 0, 0] = 1.0
+    y = y.to(DEV)
+    outy, _ = ops.pw_gemm_h3(ops.h3_pieces(w, H, B, False), y, H, B, K, ops.absmax_rows(y))
+    refy = torch.einsum("rc,mck->mrk", w.double().cpu(), y.double().cpu())
+    bound = 2.0 ** -38 * w.double().cpu().abs().sum(1).view(1, H, 1) + 6e-7 * torch.einsum("rc,mck->mrk", w.double().cpu().abs(), y.double().cpu().abs())
+    assert bool(((outy.double().cpu() - refy).abs() <= bound).all())
+    # an all-zero weight matrix
+    z = torch.zeros(H, B, device=DEV)
+    outz, _ = ops.pw_gemm_h3(ops.h3_pieces(z, H, B, False), x[:1], H, B, K, ops.absmax_rows(x[:1]))
+    assert float(outz.abs().max()) == 0.0
+
+
+def _paper_step_setup(M):
+    cfg = O.Config(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2)
+    torch.manual_seed(0)
+    m = ctn.ConvTasNet(cfg.N, cfg.L, cfg.B, cfg.H, cfg.P, cfg.X, cfg.R, cfg.C).to(DEV)
+    mix, lens, src = O.synth_batch(0, M, 32000)
+    return cfg, m, mix, lens, src
+
+
+def test_h3_paper_config_gradients_against_the_fp64_oracle():
+    """One training step of BASELINE configs[1] (M = 1): every gradient against the CPU oracle run in fp64 on the same weights,
+    under h3, b6 and the fp32 MFMA.  h3 must be at least as close to fp64 as the fp32 matrix instruction is."""
+    cfg, m, mix, lens, src = _paper_step_setup(1)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    sd = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    loss_ref = O.cal_loss(src.double(), O.forward(cfg, sd, mix.double()), lens)[0]
+    loss_ref.backward()
+    tot = sum(float((v.grad ** 2).sum()) for v in sd.values() if v.grad is not None) ** 0.5
+    err = {}
+    for arith in ("h3", "b6", "fp32"):
+        with ctn.gemm_arithmetic(arith):
+            m.zero_grad()
+            loss = ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0]
+            loss.backward()
+            ops.join_side_stream()
+            e2 = sum(float(((p.grad.double().cpu() - sd[k].grad) ** 2).sum()) for k, p in m.named_parameters())
+            err[arith] = (e2 ** 0.5 / tot, abs(float(loss.detach()) - float(loss_ref.detach())))
+    print("paper config, |g - g_fp64| / |g_fp64| and loss error [dB]: %s" % err)
+    assert err["h3"][1] < 1e-3 and err["h3"][0] < 5e-5
+    assert err["h3"][0] <= 1.1 * err["fp32"][0], err
+
+
+def test_h3_stays_as_close_to_the_fp32_mfma_trajectory_as_b6_does():
+    """10 optimiser steps (fwd + PIT loss + bwd + clip(5) + Adam, lr 1e-3) of the paper config on the bench's batch under the fp32
+    MFMA (bit-exact fp32 FMA chains), b6 and h3 from the same weights on the same data: rounding differences of a training run
+    grow step by step under ANY arithmetic; h3 must not grow them faster than b6 does."""
+    from conv_tasnet_amd.optim import FlatAdam
+    from conv_tasnet_amd.train import SyntheticLoader
+    mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=32000)))
+    mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
+    runs = {}
+    for arith in ("fp32", "b6", "h3"):
+        ctn.set_gemm_arith(arith)
+        torch.manual_seed(0)
+        m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(DEV)
+        opt = FlatAdam(m.parameters(), lr=1e-3)
+        p0 = opt.flat_params.detach().clone()
+        losses = []
+        for _ in range(10):
+            opt.zero_grad()
+            loss = ctn.cal_loss(src, m(mix), lens)[0]
+            loss.backward()
+            opt.step(max_grad_norm=5.0)
+            losses.append(float(loss.detach()))
+        runs[arith] = (losses, opt.flat_params.detach().clone(), p0)
+    ctn.set_gemm_arith(DEFAULT_ARITH)
+    l32, p32, p0 = runs["fp32"]
+    travelled = float((p32 - p0).double().norm())
+    dev = {}
+    for arith in ("b6", "h3"):
+        ls, ps, _ = runs[arith]
+        dev[arith] = (max(abs(a - b) for a, b in zip(ls, l32)), float((ps - p32).double().norm()) / travelled)
+    print("10 steps against the fp32-MFMA run: (max |loss difference| [dB], |p - p_fp32| / |p_fp32 - p0|) %s; losses %s" % (dev, l32))
+    assert l32[-1] < l32[0] - 1.0
+    assert abs(runs["h3"][0][0] - l32[0]) < 1e-4                       # the first step's loss (same weights): fp32 level
+    assert dev["h3"][0] <= 2.0 * dev["b6"][0] + 1e-3 and dev["h3"][1] <= 2.0 * dev["b6"][1] + 1e-3, dev
