@@ -35,10 +35,9 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0          # same guide, HBM3E peak
 ARITH = {"name": "h3"}         # GEMM arithmetic of this run (--arith): "h3" (library default) = the composite stacks on two fp16 pieces per
                                # fp32 operand under tracked power-of-two scales, 3 f16 MFMAs per product step (fp32-faithful products; every
-                               # other GEMM as b6), "b6" = three bf16 pieces, 6 bf16 MFMAs (fp32-faithful), "fp32" = fp32 MFMA,
-                               # "b3" = 3 bf16 MFMAs (two bf16 pieces: ~16-bit products, opt-in, NOT reference precision)
-ARITH_IDS = {"fp32": 0, "b3": 1, "b6": 2, "h3": 3}
-MFMA_PER_STEP = {"b3": 3, "b6": 6, "h3": 3}
+                               # other GEMM as b6), "b6" = three bf16 pieces, 6 bf16 MFMAs (fp32-faithful), "fp32" = fp32 MFMA
+ARITH_IDS = {"fp32": 0, "b6": 2, "h3": 3}
+MFMA_PER_STEP = {"b6": 6, "h3": 3}
 PER_GPU_BATCH = 8
 CONFIGS = {
     "paper": dict(model=dict(N=256, L=20, B=256, H=512, P=3, X=8, R=4, C=2), norm_type="gLN", causal=False, T=32000, sr=8000,
@@ -341,11 +340,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="paper")
-    ap.add_argument("--arith", choices=["h3", "b6", "fp32", "b3"], default=os.environ.get("CTN_GEMM_ARITH", "h3"),
+    ap.add_argument("--arith", choices=["h3", "b6", "fp32"], default=os.environ.get("CTN_GEMM_ARITH", "h3"),
                     help="GEMM arithmetic: h3 = the composite stacks on two fp16 pieces per fp32 operand under tracked power-of-two scales, "
                          "three f16 MFMAs per product step (fp32-faithful products; library default), b6 = three bf16 pieces per fp32 "
-                         "operand, six bf16 MFMAs (fp32-faithful), fp32 = fp32-MFMA kernels, b3 = two bf16 pieces / three MFMAs "
-                         "(~16-bit products; NOT reference precision, opt-in)")
+                         "operand, six bf16 MFMAs (fp32-faithful), fp32 = fp32-MFMA kernels")
     ap.add_argument("--no-side-arith", action="store_true", help="skip the short runs on the other arithmetics after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -429,7 +427,7 @@ def main():
             "metric": "4s 8kHz 2-spk utterances/sec (fwd+bwd)", "value": round(value, 2), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMM products from two bf16 pieces per operand: ~16 significant bits, f32 accumulate)" if args.arith == "b3" else "f32",
+            "dtype": "f32",
             "gemm_arith": args.arith, "data": "synthetic",
             "config": {"workload": (cfg["name"] % PER_GPU_BATCH) + " utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam",
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": cfg["T"],

@@ -8,10 +8,11 @@ python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err || tai
 python bench.py --config causal --no-cpu-baseline > gpurun_out/${T}_bench_causal.json 2>> gpurun_out/${T}_bench.err
 python bench.py --config c3 --no-cpu-baseline > gpurun_out/${T}_bench_c3.json 2>> gpurun_out/${T}_bench.err
 python bench.py --arith fp32 --no-cpu-baseline --no-side-arith > gpurun_out/${T}_bench_fp32.json 2>> gpurun_out/${T}_bench.err
+python bench.py --arith b6 --no-cpu-baseline --no-side-arith > gpurun_out/${T}_bench_b6.json 2>> gpurun_out/${T}_bench.err
 T=$T python - <<'PY'
 import json, os
 T = os.environ["T"]
-for f in ("bench", "bench_causal", "bench_c3", "bench_fp32"):
+for f in ("bench", "bench_causal", "bench_c3", "bench_fp32", "bench_b6"):
     j = json.loads(open("gpurun_out/%s_%s.json" % (T, f)).read().strip().splitlines()[-1])
     r = j["roofline"]
     print(f, {k: j[k] for k in ("value", "ms_per_step", "host_issue_ms_per_step", "mean_loss", "gemm_arith", "dtype")}, "dominant:", r["kernel"][:40], r["bound"], r["frac"], r["traffic"],
@@ -26,6 +27,6 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${T} -o p --output-format
 cd $R
 cp $(ls gpurun_out/prof_${T}/*kernel_stats.csv gpurun_out/prof_${T}/*/*kernel_stats.csv 2>/dev/null | head -1) gpurun_out/${T}_kernel_stats_bench_steps5.csv
 python benchmarks/kstats.py gpurun_out/prof_${T} 7 14
-bash benchmarks/pmc_traffic.sh pw_wgrad_b3_kernel benchmarks/b3_only.py gpurun_out/${T}_pmc_b6_wgrad_dW2_pro.json "B2 weight gradient dW2 (gLN prologue)" "W2 30" b6 | tail -12
-bash benchmarks/pmc_traffic.sh pw_gemm_b3p_kernel benchmarks/b3_only.py gpurun_out/${T}_pmc_b6_B1.json "B1 input gradient W2^T.dout (+ gLN backward sums)" "B1 30" b6 | tail -4
+bash benchmarks/pmc_traffic.sh pw_wgrad_b3_kernel benchmarks/b3_only.py gpurun_out/${T}_pmc_h3_wgrad_dW2_pro.json "B2 weight gradient dW2 (gLN prologue)" "W2 30" h3 | tail -12
+bash benchmarks/pmc_traffic.sh pw_gemm_b3p_kernel benchmarks/b3_only.py gpurun_out/${T}_pmc_h3_B1.json "B1 input gradient W2^T.dout (+ gLN backward sums)" "B1 30" h3 | tail -4
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -430,19 +430,19 @@ int g_ctn_tile_override = -2;
 
 // GEMM arithmetic (ctn_gemm_b3.h): 3 = "h3" (default: the composite stacks run their GEMMs on two fp16 pieces per operand under
 // tracked power-of-two scales, three f16 MFMAs -- the ctn_*_h3 entry points; every other GEMM as b6), 2 = "b6" (three bf16 pieces
-// per operand, six bf16 MFMAs, fp32 accumulation), 1 = "b3" (two bf16 pieces, three MFMAs: ~16-bit products, opt-in), 0 = fp32
-// MFMA (bit-exact fp32 FMA chains).  CTN_GEMM_ARITH=h3|b6|b3|fp32, ctn_tune("arith", 3|2|1|0).  Layers with fewer than 64 output
-// rows (the decoder's basis GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
+// per operand, six bf16 MFMAs, fp32 accumulation), 0 = fp32 MFMA (bit-exact fp32 FMA chains).  (1 was round 2's ~16-bit "b3":
+// removed.)  CTN_GEMM_ARITH=h3|b6|fp32, ctn_tune("arith", 3|2|0).  Layers with fewer than 64 output rows (the decoder's basis
+// GEMM) and weight gradients with a side below 32 stay on the fp32 kernels.
 static int g_arith = -1;
 static int arith_id() {
     if (g_arith < 0) {
         const char* e = getenv("CTN_GEMM_ARITH");
-        g_arith = (e && !strcmp(e, "fp32")) ? 0 : (e && !strcmp(e, "b3")) ? 1 : (e && !strcmp(e, "b6")) ? 2 : 3;
+        g_arith = (e && !strcmp(e, "fp32")) ? 0 : (e && !strcmp(e, "b6")) ? 2 : 3;
     }
     return g_arith;
 }
-// kernel arithmetic id (template parameter AR of ctn_gemm_b3.h) of the plain entry points: 0 fp32 MFMA, 2 b3, 3 b6 (also under h3)
-static int arith_np() { return arith_id() == 0 ? 0 : (arith_id() == 1 ? 2 : 3); }
+// kernel arithmetic id (template parameter AR of ctn_gemm_b3.h) of the plain entry points: 0 fp32 MFMA, 3 b6 (also under h3)
+static int arith_np() { return arith_id() == 0 ? 0 : 3; }
 static bool b3_fwd(int R) { return arith_id() != 0 && R >= 64; }
 static bool b3_wgrad(int R, int Cn) { return arith_id() != 0 && R >= 32 && Cn >= 32; }
 
@@ -648,14 +648,14 @@ static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int*
 }
 
 // Library switches for in-process A/B runs and the test-suite (process-global: call them from the thread that issues the work,
-// between steps).  Keys: "arith" (2 b6, 1 b3, 0 fp32 MFMA), "b3_tile" (0 128x128, 1 128x64, 2 256x64: tile of the split-bf16
+// between steps).  Keys: "arith" (3 h3, 2 b6, 0 fp32 MFMA), "b3_tile" (0 128x128, 1 128x64, 2 256x64: tile of the split-bf16
 // forward / input-gradient kernels), "b3_tile_k3" (the same for the prologue + residual form), "b3_wgrad_blocks" / "wgrad_blocks"
 // (target workgroups per weight-gradient launch, split-bf16 / fp32), "pw_tile" (fp32 forward tile id 0..3, -1 = default).
 int ctn_tune(const char* key, int value) {
     if (!key) return CTN_ERR_ARG;
     if (!strcmp(key, "pw_tile") && value >= -1 && value <= 3) g_ctn_tile_override = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
-    else if (!strcmp(key, "arith") && value >= 0 && value <= 3) g_arith = value;
+    else if (!strcmp(key, "arith") && (value == 0 || value == 2 || value == 3)) g_arith = value;
     else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 2) g_ctn_b3_tile = value;
     else if (!strcmp(key, "b3_tile_k3") && value >= 0 && value <= 2) g_ctn_b3_tile_k3 = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;

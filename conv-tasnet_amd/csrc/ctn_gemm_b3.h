@@ -1,27 +1,33 @@
-// Split-bf16 arithmetic of the 1x1-convolution GEMMs: fp32 operands multiplied on the bf16 matrix cores as NP bf16 pieces each.
+// Split arithmetics of the 1x1-convolution GEMMs: fp32 operands multiplied on the bf16 / f16 matrix cores as pieces.
 //
-//   NP = 3, "b6" (library default -- fp32-faithful products):
+//   "h3" (library default for the composite stacks; template id AR = 5, A/B builds 4):
+//     a s = a0 + a1 + r,  a0 = fp16_rne(a s), a1 = fp16_rne(a s - a0) (exact difference): two 11-bit significands and the sign of
+//     a1 hold 23-24 bits, |r| <= 2^-24 |a s|;  a.b ~= (a1.b0 + a0.b1 + a0.b0) / (s_a s_b): THREE v_mfma_f32_32x32x16_f16, fp32
+//     accumulation; dropped: a1.b1 + r_a.b + a.r_b <= 3 * 2^-24 |a.b|.  s = an exact power of two per operand from a bound on its
+//     magnitude -- the weight's own maximum, and for activations the per-utterance maximum TRACKED BY THE PRODUCING KERNEL
+//     (CTN_AMAX_SLOTS words per utterance, atomic max of bit patterns: exact and order-free).  The low piece is stored times 2^11
+//     and its two cross products have an accumulator of their own, so it is a normal fp16 number for every element down to 2^-27
+//     of the bound.  Measured against fp64 (benchmarks/h3_check.py): max error 1.5e-7 of sum |a||b| (rms 1.3e-8) on every form and
+//     on operands 1e-20 .. 1e6 / utterances 2^80 apart / heavy tails, against 3.9e-7 (2.3e-8) for b6 and 3.8e-7 (2.8e-8) for the
+//     fp32 MFMA: the f16 MFMA rounds once per 16-deep step.
+//   "b6" (NP = 3 bf16 pieces; every GEMM outside the composite stacks, and the stacks under CTN_GEMM_ARITH=b6):
 //     a = a0 + a1 + a2 EXACTLY,  a0 = bf16_rne(a), a1 = bf16_rne(a - a0), a2 = a - a0 - a1   (both differences are exact in fp32;
 //     |a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|, and a2 has at most 8 significant bits, so its conversion is exact as well)
 //     a.b ~= a2.b0 + a0.b2 + a1.b1 + a1.b0 + a0.b1 + a0.b0       six bf16 MFMAs per 16-deep step, fp32 accumulation;
 //     dropped: a1.b2 + a2.b1 + a2.b2, |.| <= (2 * 2^-24 + 2^-32) |a.b| -- the size of ONE fp32 rounding of the product, which the
-//     fp32 FMA chain of the reference commits at every step as well.  Measured against fp64 (benchmarks/b3_check.py): the error of
-//     every GEMM form is that of the fp32-MFMA kernels.
-//   NP = 2, "b3" (opt-in, faster, NOT fp32-faithful):
-//     a = a0 + a1 + ra, |ra| <= 2^-16 |a|;  a.b ~= a1.b0 + a0.b1 + a0.b0;  dropped: a1.b1 (<= 2^-16 |a.b|) and both remainder
-//     terms ra.b, a.rb (<= 2^-16 |a.b| each): products carry ~16 significant bits.
+//     fp32 FMA chain of the reference commits at every step as well.
+//   (Round 2's two-piece bf16 "b3" -- ~16-bit products, not reference precision -- is gone: h3 costs the same three MFMAs.)
 //
-// Each piece-product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (8 x 8-bit significands).  Why not the fp32
-// MFMA: it runs at 1/16 of the bf16 rate, so six bf16 MFMAs cost 3/8 of one fp32 MFMA of the same shape, and the fp32-MFMA
-// training step sits AT the 1400 W package power cap where its time is its energy.
-// CTN_GEMM_ARITH=b6|b3|fp32 / ctn_tune("arith", 2|1|0) select the arithmetic; fp32 = the fp32-MFMA kernels of ctn_gemm.hip.
+// Why not the fp32 MFMA: it runs at 1/16 of the bf16 / f16 rate, and the fp32-MFMA training step sits AT the 1400 W package power
+// cap where its time is its energy.
+// CTN_GEMM_ARITH=h3|b6|fp32 / ctn_tune("arith", 3|2|0) select the arithmetic; fp32 = the fp32-MFMA kernels of ctn_gemm.hip.
 //
 // Same contracts as the fp32 kernels (PwArgs / WgArgs, prologues, epilogues, tile order, fixed-order reductions).  Activation
 // operands are split on the fly while they are staged global -> registers -> LDS (after the fused prologue), so no pre-split
-// activation copies exist in HBM; weights are either split the same way (raw ctn_pw_gemm on fp32 weights) or pre-split once
-// per stack call into MFMA-fragment order (ctn_split_b3_batch, the product path of the composite stacks).  Operands whose
-// contraction index is strided in memory (activations [channel][frame], weights given as [contraction][row]) are stored
-// channel-major in LDS and read with ds_read_b64_tr_b16, the hardware transposing read; operands with a contiguous
+// activation copies exist in HBM; weights are either split the same way (raw ctn_pw_gemm on fp32 weights, b6) or pre-split once
+// per stack call into MFMA-fragment order (ctn_split_b3_batch / ctn_split_h3_batch, the product path of the composite stacks).
+// Operands whose contraction index is strided in memory (activations [channel][frame], weights given as [contraction][row]) are
+// stored channel-major in LDS and read with ds_read_b64_tr_b16, the hardware transposing read; operands with a contiguous
 // contraction (stored [row][contraction] weights, both operands of the weight gradient) are stored row-major and read with
 // ds_read_b128.
 // Included by ctn_gemm.hip (the argument structs live in that translation unit's anonymous namespace).
@@ -34,7 +40,7 @@ namespace {
 constexpr int XK = 32;               // contraction steps per k-tile (two MFMA steps of depth 16)
 constexpr int XPA = XK + 8;          // row pitch of a row-major piece plane in bf16 (80 B: conflict-free ds_read_b128 over 16 rows)
 
-// Arithmetic ids of the kernels below (template parameter AR): 2 = b3, 3 = b6 (NP = AR bf16 pieces), 4 / 5 = h3 (two fp16 pieces).
+// Arithmetic ids of the kernels below (template parameter AR): 3 = b6 (three bf16 pieces), 4 / 5 = h3 (two fp16 pieces).
 // 5 (the one built into the library, CTN_H3_AR) stores the low piece multiplied by 2^11 and sums the two cross products in an
 // accumulator of their own (W2): the low piece then stays a NORMAL fp16 number for every element down to 2^-27 of its operand's
 // bound instead of 2^-16 (id 4: both pieces at one scale, one accumulator -- kept for A/B builds, -DCTN_H3_AR=4).
@@ -68,7 +74,7 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {          // round
 // PRESCALED: v already carries the scale (folded into the operand prologue's constants: a power of two commutes with rounding).
 template <int AR, bool PRESCALED = false>
 __device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[Ar<AR>::NP], float s) {
-    static_assert(AR >= 2 && AR <= 5, "b3, b6 or h3");
+    static_assert(AR >= 3 && AR <= 5, "b6 or h3");
     if constexpr (Ar<AR>::F16) {
         // a s = a0 + a1 + r:  a0 = f16_rne(a s), a1 = f16_rne(a s - a0) (the difference is exact in fp32), |r| <= 2^-24 |a s| as
         // long as a1 is a normal fp16 number, |r| <= 2^-25 (half an fp16 subnormal step) below that.  W2: the stored low piece
@@ -181,7 +187,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* plane_at_tile, int P, in
 template <int AR, typename TL, int TRANS_W, int PRO, int EPI>
 __global__ __launch_bounds__(TL::NTH, (TL::TM * TL::TN <= 4096) ? 4 : ((TL::TM * TL::TN <= 8192 && AR == 2) ? 3 : 2))
 void pw_gemm_b3_kernel(PwArgs a) {
-    static_assert(AR == 2 || AR == 3, "fp32 weights split on the fly: the bf16 arithmetics only (h3 needs the weight's range)");
+    static_assert(AR == 3, "fp32 weights split on the fly: b6 only (h3 needs the weight's range)");
     constexpr int NP = Ar<AR>::NP;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, WN = TL::WN, NTH = TL::NTH;
     using L = B3<TL, TRANS_W, NP>;
@@ -522,7 +528,7 @@ __device__ unsigned long long ctn_dbg_tl[8192 * 12];
 #endif
 
 template <int AR, typename TL, int PRO, int EPI>
-__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? ((Ar<AR>::NP == 2 && !Ar<AR>::W2) ? 4 : 3) : 2)
+__global__ __launch_bounds__(TL::NTH, (TL::MT * TL::NTL <= 2) ? (Ar<AR>::NP == 2 ? 4 : 3) : 2)
 void pw_gemm_b3p_kernel(PwArgs a) {
     constexpr int NP = Ar<AR>::NP;
     constexpr int TM = TL::TM, TN = TL::TN, MT = TL::MT, NTL = TL::NTL, WM = TL::WM, NTH = TL::NTH;
@@ -678,9 +684,26 @@ void pw_gemm_b3p_kernel(PwArgs a) {
 
     // k-tile kt: weight fragments in one register set, activation tile in LDS stage kt & 1; while it is multiplied, tile
     // kt + 1 (already in registers) is split into the other stage and the loads of tile kt + 2 are issued.
-    bf16x8 fa0[MT][2][NP], fa1[MT][2][NP];
     float4 rb[B_L];
     float2 rp[B_L];
+    // Two accumulator sets (W2) on the 128 x 64 tile: ONE weight-fragment register set, reloaded right behind the MFMAs that read
+    // it, keeps the kernel at 113-127 VGPRs = four workgroups per CU (two sets: 138 VGPRs, three workgroups; in-step 762 vs 747
+    // utt/s on one box).  The other waves of the SIMD cover the reload.
+    if constexpr (Ar<AR>::W2 && MT * NTL <= 2) {
+        bf16x8 fa[MT][2][NP];
+        load_a(0, fa);
+        load_b(0, rb, rp);
+        store_b(0, rb, rp);
+        if (nk > 1) load_b(1, rb, rp);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            compute(kt & 1, fa);
+            if (kt + 1 < nk) { load_a(kt + 1, fa); store_b((kt + 1) & 1, rb, rp); }
+            __syncthreads();
+            if (kt + 2 < nk) load_b(kt + 2, rb, rp);
+        }
+    } else {
+    bf16x8 fa0[MT][2][NP], fa1[MT][2][NP];
     load_a(0, fa0);
     load_b(0, rb, rp);
     store_b(0, rb, rp);
@@ -698,6 +721,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
             __syncthreads();
             if (kt + 3 < nk) { load_a(kt + 3, fa1); load_b(kt + 3, rb, rp); }
         }
+    }
     }
     CTN_TL_STAMP(2);
 #ifdef CTN_EXP_B3_NOEPI
@@ -829,7 +853,7 @@ void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool 
 
 }  // namespace
 
-// ---- host side, used by the entry points of ctn_gemm.hip (ar = arithmetic id of the kernels: 3 = b6, 2 = b3, 4 = h3) -------------
+// ---- host side, used by the entry points of ctn_gemm.hip (ar = arithmetic id of the kernels: 3 = b6, 4 = h3) ----------------------
 static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step (b3) 11.56 / 11.20 / 11.50 ms
 static int g_ctn_b3_wgrad_blocks = 256;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
@@ -872,8 +896,7 @@ static void ctn_b3_launch_fwd(int ar, PwArgs& a, int trans_w, bool pro, bool res
     a.tiles_r = ctn_cdiv(a.R, d[tile][0]);
     a.tiles_c = ctn_cdiv(a.Kp, d[tile][1]);
     if (ar == 4) ctn_b3_launch_fwd_np<H3AR>(tile, a, 2, pro, residual, stats, relu, gln_bwd, st);       // h3 (pre-split weights only)
-    else if (ar == 3) ctn_b3_launch_fwd_np<3>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
-    else ctn_b3_launch_fwd_np<2>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
+    else ctn_b3_launch_fwd_np<3>(tile, a, trans_w, pro, residual, stats, relu, gln_bwd, st);
 }
 
 // bytes of one pre-split weight operand; h3 appends 16 bytes: the bit pattern of max |W| (the scale is derived from it)
@@ -909,8 +932,7 @@ static void ctn_b3_launch_split(int ar, const void* const* src, void* const* dst
         sa.nkt = (Cn + XK - 1) / XK * 2;
         const dim3 grid(ctn_cdiv(sa.nkt, 4), (R + 31) / 32, cnt);
         if (ar == 4) hipLaunchKernelGGL(split_b3_kernel<H3AR>, grid, dim3(256), 0, st, sa);
-        else if (ar == 3) hipLaunchKernelGGL(split_b3_kernel<3>, grid, dim3(256), 0, st, sa);
-        else hipLaunchKernelGGL(split_b3_kernel<2>, grid, dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL(split_b3_kernel<3>, grid, dim3(256), 0, st, sa);
     }
 }
 
@@ -939,7 +961,6 @@ static int ctn_b3_launch_wgrad(int ar, WgArgs& a, bool pro, hipStream_t st) {
     const int nsplit = a.M * a.chunks_per_m;
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * nsplit));
     if (ar == 4) ctn_b3_launch_wgrad_np<H3AR>(a, pro, grid, st);
-    else if (ar == 3) ctn_b3_launch_wgrad_np<3>(a, pro, grid, st);
-    else ctn_b3_launch_wgrad_np<2>(a, pro, grid, st);
+    else ctn_b3_launch_wgrad_np<3>(a, pro, grid, st);
     return nsplit;
 }

@@ -27,21 +27,21 @@ F64 = torch.float64
 BF16 = torch.bfloat16
 
 AMAX_SLOTS = 64        # CTN_AMAX_SLOTS of include/ctn_hip.h
-_ARITH_NAMES = ("fp32", "b3", "b6", "h3")        # ids of ctn_gemm_arith / ctn_tune("arith", id)
+_ARITH_NAMES = ("fp32", None, "b6", "h3")        # ids of ctn_gemm_arith / ctn_tune("arith", id)  (1 was round 2's b3: removed)
 
 
 def gemm_arith():
     """'h3' (default: the composite stacks multiply two fp16 pieces per fp32 operand under tracked power-of-two scales, three f16
     MFMAs, fp32 accumulation -- fp32-faithful products; every other GEMM as b6), 'b6' (three bf16 pieces per operand, six bf16
-    MFMAs), 'fp32' (fp32-MFMA kernels, bit-exact fp32 FMA chains) or 'b3' (opt-in: two bf16 pieces, three MFMAs, ~16-bit products)."""
+    MFMAs) or 'fp32' (fp32-MFMA kernels, bit-exact fp32 FMA chains)."""
     return _ARITH_NAMES[lib.ctn_gemm_arith()]
 
 
 def set_gemm_arith(name):
     """Select the arithmetic of every 1x1-convolution GEMM (include/ctn_hip.h: ctn_gemm_arith).  Change it between steps
     only: statistics layouts and workspace sizes depend on it (the cached workspaces are dropped here)."""
-    if name not in _ARITH_NAMES:
-        raise ValueError("gemm arithmetic must be one of %s" % (_ARITH_NAMES,))
+    if name is None or name not in _ARITH_NAMES:
+        raise ValueError("gemm arithmetic must be one of %s" % ([n for n in _ARITH_NAMES if n],))
     lib.call("ctn_tune", b"arith", _ARITH_NAMES.index(name))
     _ws_cache.clear()
 
@@ -929,35 +929,17 @@ def bn_bwd(dOut, Y, alpha, weight, mr, training, K):
     return dY, dg, db, dalpha
 
 
-class _bn_arith:
-    """BatchNorm blocks never run on the opt-in b3 arithmetic: near-constant channels (rstd ~ 1e4 at random init) amplify
-    its ~16-bit product noise to tens of percent of a BN layer's gradient.  Under b3 their GEMMs use the default b6."""
-
-    def __enter__(self):
-        self.prev = gemm_arith()
-        if self.prev == "b3":
-            set_gemm_arith("b6")
-        return self
-
-    def __exit__(self, *exc):
-        if self.prev == "b3":
-            set_gemm_arith("b3")
-        return False
-
-
 class BnBlock(torch.autograd.Function):
     """TemporalBlock with norm_type="BN" (src/conv_tasnet.py:218-244,305-309): same chain as ClnBlock with the two
     norms replaced by (PReLU +) BatchNorm1d.  bn1 / bn2 = (running_mean, running_var, training, eps, momentum)."""
 
     @staticmethod
     def forward(ctx, *args):
-        with _bn_arith():
-            return BnBlock._forward(ctx, *args)
+        return BnBlock._forward(ctx, *args)
 
     @staticmethod
     def backward(ctx, dout):
-        with _bn_arith():
-            return BnBlock._backward(ctx, dout)
+        return BnBlock._backward(ctx, dout)
 
     @staticmethod
     def _forward(ctx, x, w1, a1, g1, b1, D, a2, g2, b2, w2, K, dilation, causal, bn1, bn2):

@@ -28,8 +28,7 @@ def golden():
 # "h3" (library default): the composite stacks multiply two fp16 pieces per fp32 operand under tracked power-of-two scales (three
 # f16 MFMAs, fp32 accumulation; every other GEMM as b6); "b6": three bf16 pieces per fp32 operand, six bf16 MFMAs (csrc/ctn_gemm_b3.h);
 # "fp32": fp32-MFMA kernels (bit-exact fp32 FMA chains).  Every limit asserted in the GPU tests is the fp32 limit and applies
-# UNCHANGED to all three (TOL_SCALE = 1).  The opt-in ~16-bit "b3" arithmetic (two bf16 pieces, three MFMAs) is not part of this
-# fixture: tests/test_gpu_b3.py holds its own, explicitly stated limits; tests/test_gpu_h3.py tests the h3 entry points themselves.
+# UNCHANGED to all three (TOL_SCALE = 1).  tests/test_gpu_h3.py tests the h3 entry points themselves.
 ARITH = {"name": "fp32"}
 TOL_SCALE = {"fp32": 1.0, "b6": 1.0, "h3": 1.0}
 DEFAULT_ARITH = "h3"

@@ -12,14 +12,14 @@ What is asserted, with the limits of the fp32 arithmetic (nothing is widened for
   * edge cases: an all-zero utterance, NaN / inf confined to their utterance, elements far below their utterance's maximum
     (absolute error <= 2^-38 of the maximum: graceful, documented loss of RELATIVE precision);
   * at the paper config: the gradients of one training step against the fp64 CPU oracle -- h3's error is not above the fp32
-    MFMA's (observed 4.6e-6 against 1.5e-5 and 1.8e-5 for b6, benchmarks/arith_grad_err.py) -- and a 10-step trajectory: h3 stays
-    as close to the fp32-MFMA run as b6 does.
+    MFMA's (observed 2.7e-6 against 1.5e-5 and 1.8e-5 for b6, benchmarks/arith_grad_err.py) -- and a 10-step trajectory against
+    the same 10 steps of the oracle in fp64: h3 follows it at least as closely as the fp32 MFMA does.
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import DEFAULT_ARITH
+from conftest import DEFAULT_ARITH, load_golden
 from oracle import ctn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -173,6 +173,24 @@ def test_h3_producers_track_exact_maxima():
     ctn.lib.call("ctn_gln_prelu_bwd", dn.data_ptr(), y.data_ptr(), dY.data_ptr(), M, H, K, Kp, gam.data_ptr(), a.data_ptr(), ms.data_ptr(),
                  s1p.data_ptr(), H, dap.data_ptr(), am.data_ptr(), ops._stream())
     assert torch.equal(amax_f(am), dY.abs().amax((1, 2)))
+    # channel-wise LayerNorm (the causal config's norm): forward output and input gradient, fast (v4) and fallback kernels
+    for Ch, Kc in ((H, 700), (36, 203)):
+        Kpc = ops.padded_frames(Kc)
+        yc = pad(torch.randn(M, Ch, Kc, generator=g(7)) * torch.tensor([1e-6, 1.0, 3e4]).view(M, 1, 1), Kpc).to(DEV)
+        gc, bc = torch.randn(Ch, generator=g(8)).to(DEV), torch.randn(Ch, generator=g(9)).to(DEV)
+        out, mean, rstd = torch.empty_like(yc), torch.empty(M, Kpc, device=DEV), torch.empty(M, Kpc, device=DEV)
+        am = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+        ctn.lib.call("ctn_cln_fwd", yc.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, Ch, Kc, Kpc, gc.data_ptr(), bc.data_ptr(),
+                     a.data_ptr(), am.data_ptr(), ops._stream())
+        assert torch.equal(amax_f(am), out.abs().amax((1, 2)))
+        dO = pad(torch.randn(M, Ch, Kc, generator=g(10)), Kpc).to(DEV)
+        dYc = torch.empty_like(yc)
+        pc = torch.empty(ctn.lib.ctn_cln_bwd_pc_floats(M, Ch, Kpc), device=DEV)
+        dapc = torch.empty(ctn.lib.ctn_cln_bwd_blocks(M, Kpc), device=DEV)
+        am = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+        ctn.lib.call("ctn_cln_bwd", dO.data_ptr(), yc.data_ptr(), dYc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, Ch, Kc, Kpc, gc.data_ptr(),
+                     a.data_ptr(), 0, 0, dapc.data_ptr(), pc.data_ptr(), am.data_ptr(), ops._stream())
+        assert torch.equal(amax_f(am), dYc.abs().amax((1, 2)))
 
 
 def test_h3_edge_cases():
@@ -238,37 +256,37 @@ def test_h3_paper_config_gradients_against_the_fp64_oracle():
     assert err["h3"][0] <= 1.1 * err["fp32"][0], err
 
 
-def test_h3_stays_as_close_to_the_fp32_mfma_trajectory_as_b6_does():
+def test_trajectories_against_the_fp64_oracle():
     """10 optimiser steps (fwd + PIT loss + bwd + clip(5) + Adam, lr 1e-3) of the paper config on the bench's batch under the fp32
-    MFMA (bit-exact fp32 FMA chains), b6 and h3 from the same weights on the same data: rounding differences of a training run
-    grow step by step under ANY arithmetic; h3 must not grow them faster than b6 does."""
+    MFMA, b6 and h3, from the same weights on the same data, against the SAME 10 steps of the CPU oracle run in fp64
+    (tests/golden/paper_traj_fp64.npz, oracle/make_traj_golden.py).  Observed on the MI355X: every fp32-accumulating arithmetic
+    (fp32 MFMA, b6 -- and the CPU in fp32, benchmarks/trajectory_vs_oracle.py) drifts from the fp64 run by the same ~4e-3 dB /
+    1.4 % of the distance travelled, together (they round alike); h3, whose f16 MFMAs accumulate 16-deep steps before rounding,
+    stays within 1e-4 dB.  Asserted: h3 follows the fp64 trajectory at least as closely as the fp32 MFMA does."""
     from conv_tasnet_amd.optim import FlatAdam
     from conv_tasnet_amd.train import SyntheticLoader
-    mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=32000)))
+    gd = load_golden("paper_traj_fp64")
+    steps, stride = int(gd["steps"]), int(gd["stride"])
+    mix, lens, src = next(iter(SyntheticLoader(1, int(gd["M"]), samples=32000)))
     mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
-    runs = {}
+    dev = {}
     for arith in ("fp32", "b6", "h3"):
         ctn.set_gemm_arith(arith)
         torch.manual_seed(0)
         m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(DEV)
         opt = FlatAdam(m.parameters(), lr=1e-3)
-        p0 = opt.flat_params.detach().clone()
         losses = []
-        for _ in range(10):
+        for _ in range(steps):
             opt.zero_grad()
             loss = ctn.cal_loss(src, m(mix), lens)[0]
             loss.backward()
             opt.step(max_grad_norm=5.0)
             losses.append(float(loss.detach()))
-        runs[arith] = (losses, opt.flat_params.detach().clone(), p0)
+        p = torch.cat([q.detach().reshape(-1) for _, q in m.named_parameters()])[::stride].double().cpu().numpy()
+        dev[arith] = (max(abs(a - b) for a, b in zip(losses, gd["losses"])),
+                      float(np.linalg.norm(p - gd["p_final"].astype(np.float64)) / np.linalg.norm(gd["p_final"].astype(np.float64) - gd["p0"].astype(np.float64))))
     ctn.set_gemm_arith(DEFAULT_ARITH)
-    l32, p32, p0 = runs["fp32"]
-    travelled = float((p32 - p0).double().norm())
-    dev = {}
-    for arith in ("b6", "h3"):
-        ls, ps, _ = runs[arith]
-        dev[arith] = (max(abs(a - b) for a, b in zip(ls, l32)), float((ps - p32).double().norm()) / travelled)
-    print("10 steps against the fp32-MFMA run: (max |loss difference| [dB], |p - p_fp32| / |p_fp32 - p0|) %s; losses %s" % (dev, l32))
-    assert l32[-1] < l32[0] - 1.0
-    assert abs(runs["h3"][0][0] - l32[0]) < 1e-4                       # the first step's loss (same weights): fp32 level
-    assert dev["h3"][0] <= 2.0 * dev["b6"][0] + 1e-3 and dev["h3"][1] <= 2.0 * dev["b6"][1] + 1e-3, dev
+    print("10 steps against the fp64 oracle: (max |loss difference| [dB], |p - p_fp64| / |p_fp64 - p0| on every %dth parameter) %s" % (stride, dev))
+    assert gd["losses"][-1] < gd["losses"][0] - 1.0
+    assert dev["h3"][0] < 1e-3                                              # the north star's loss budget, over a whole trajectory
+    assert dev["h3"][0] <= dev["fp32"][0] + 1e-5 and dev["h3"][1] <= dev["fp32"][1] + 1e-4, dev
