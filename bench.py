@@ -197,7 +197,7 @@ def _gemm_bytes(name, a, K):
 
 def family_table(probe, stack, cfg, K, steps):
     """Per kernel family: launches, in-step time, and the roofline that binds it.  A GEMM family is priced against BOTH
-    roofs -- executed MFMA FLOPs (3 bf16 MFMAs per algorithmic product step under b3, 1 fp32 MFMA under fp32) over the
+    roofs -- executed MFMA FLOPs (3 f16 MFMAs per algorithmic product step under h3, 6 bf16 under b6, 1 fp32 MFMA under fp32) over the
     dense peak of that MFMA type, and algorithmic bytes over 8 TB/s -- and reports the binding (larger) bound."""
     c = cfg["model"]
     M, H = PER_GPU_BATCH, c["H"]

@@ -48,7 +48,7 @@ int ctn_stream_order(void* from, void* to);
 /* Out[m] = op(W) . f(X[m])  (+ residual[m]),   X:[M,Cn,Kp]  Out:[M,R,Kp]
  *   trans_w = 0: W is [R,Cn] (forward);  trans_w = 1: W is [Cn,R] (input gradient, or forward on a transposed copy:
  *     the fast form of the fp32-MFMA arithmetic -- ctn_transpose_batch);  trans_w = 2: W is a block of pre-split bf16 pieces
- *     from ctn_split_b3_batch (split-bf16 arithmetics b6 / b3, R >= 64: the fast form there).
+ *     from ctn_split_b3_batch (b6 arithmetic, R >= 64: the fast form there).
  *   pro_part != NULL: f(x)[i,k] = gamma[i]*((prelu(x,alpha)-mean_m)*rstd_m)+beta[i]
  *     for k < K, 0 otherwise; (mean_m, rstd_m) are finalised from the [M, pro_nparts, 2] fp64
  *     (sum, sum of squares) partials of prelu(x) -- global LayerNorm, src/conv_tasnet.py:358-360 --
@@ -96,13 +96,13 @@ int ctn_tune(const char* key, int value);
  *       the dropped terms are <= 2^-23 |a.b| -- one fp32 rounding of the product.  Measured against fp64 the error of every
  *       GEMM form is that of the fp32 MFMA (3.4e-7 vs 4.0e-7 of sum |a||b|, profiles/r03_a_b6_check.txt);
  *   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-exact fp32 FMA chains;
- *   1 = "b3" (opt-in, NOT reference precision): two pieces per operand, three products, ~16 significant bits per product.
- * Selected by CTN_GEMM_ARITH=h3|b6|fp32|b3 at first use or ctn_tune("arith", 3|2|0|1) between steps; layers with fewer than 64
+ *   (1 was round 2's two-piece bf16 "b3", ~16-bit products: removed -- h3 costs the same three MFMAs at reference precision.)
+ * Selected by CTN_GEMM_ARITH=h3|b6|fp32 at first use or ctn_tune("arith", 3|2|0) between steps; layers with fewer than 64
  * output rows (and weight gradients with a side below 32) always use the fp32-MFMA kernels. */
 int ctn_gemm_arith(void);
-/* Split-bf16 arithmetics only: the weight operand pre-split once per step.  dst[i] receives the bf16 pieces of the GEMM operand
+/* b6 arithmetic (also the plain entry points under h3): the weight operand pre-split once per step.  dst[i] receives the bf16 pieces of the GEMM operand
  * A [R, Cn] (rows = output channels of THAT GEMM, Cn = its contraction) in MFMA fragment order, zero-filled to multiples
- * of 32: ctn_split_b3_bytes(R, Cn) bytes each (three pieces under b6, two under b3), 16-byte aligned.  k_major = 0: src[i] is
+ * of 32: ctn_split_b3_bytes(R, Cn) bytes each (three pieces), 16-byte aligned.  k_major = 0: src[i] is
  * stored [R, Cn] (forward layers); k_major = 1: src[i] is stored [Cn, R] and used transposed (input gradients of the same
  * layers).  HOST arrays of device pointers, any n.  ctn_pw_gemm(trans_w = 2) and ctn_pw_dgrad_gln_planes take such a block as
  * W: no conversion work and no LDS traffic for the weights inside the GEMM; results are bitwise those of the fp32-weight forms. */
