@@ -656,8 +656,8 @@ int ctn_tune(const char* key, int value) {
     if (!strcmp(key, "pw_tile") && value >= -1 && value <= 3) g_ctn_tile_override = value;
     else if (!strcmp(key, "wgrad_blocks") && value >= 1) g_wgrad_blocks = value;
     else if (!strcmp(key, "arith") && (value == 0 || value == 2 || value == 3)) g_arith = value;
-    else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 2) g_ctn_b3_tile = value;
-    else if (!strcmp(key, "b3_tile_k3") && value >= 0 && value <= 2) g_ctn_b3_tile_k3 = value;
+    else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 3) g_ctn_b3_tile = value;
+    else if (!strcmp(key, "b3_tile_k3") && value >= 0 && value <= 3) g_ctn_b3_tile_k3 = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;

@@ -854,14 +854,16 @@ void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool 
 }  // namespace
 
 // ---- host side, used by the entry points of ctn_gemm.hip (ar = arithmetic id of the kernels: 3 = b6, 4 = h3) ----------------------
-static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64   (ctn_tune("b3_tile", id)); in-step (b3) 11.56 / 11.20 / 11.50 ms
+static int g_ctn_b3_tile = 1;               // 0: 128x128, 1: 128x64, 2: 256x64, 3: 256x64 on 8 waves   (ctn_tune("b3_tile", id)); in-step (h3) . / 10.70 / 11.19 / 10.85 ms
 static int g_ctn_b3_wgrad_blocks = 256;     // target workgroups per weight-gradient launch   (ctn_tune("b3_wgrad_blocks", n))
 
-static int g_ctn_b3_tile_k3 = 2;            // tile of the K3 form (operand prologue + residual on pre-split weights, <= 256 rows): 256x64 =
+static int g_ctn_b3_tile_k3 = 3;            // tile of the K3 form (operand prologue + residual on pre-split weights, <= 256 rows): 256x64 =
                                             // one workgroup per column tile, so the PReLU+gLN prologue and the split of the activation tile run
-                                            // once instead of once per 128-row tile (b6, alone: 45 vs 54 us); ctn_tune("b3_tile_k3", id)
+                                            // once instead of once per 128-row tile (b6, alone: 45 vs 54 us); id 3 = the same tile on 8 waves of
+                                            // 32 rows (two accumulator sets fit 128 VGPRs: 4 waves per SIMD instead of 2; h3 in-step 10.85 vs
+                                            // 10.91 ms); ctn_tune("b3_tile_k3", id)
 static void ctn_b3_tile_dims(int* tm, int* tn) {    // the tile of every form that writes statistics partials (their count is part of the ABI)
-    static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
+    static const int d[4][2] = {{128, 128}, {128, 64}, {256, 64}, {256, 64}};
     *tm = d[g_ctn_b3_tile][0];
     *tn = d[g_ctn_b3_tile][1];
 }
@@ -877,6 +879,7 @@ static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, boo
         switch (tile) {
             case 1: launch_b3p_tile<AR, Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
             case 2: launch_b3p_tile<AR, Tile<256, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
+            case 3: launch_b3p_tile<AR, Tile<256, 64, 8, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;      // 8 waves of 32 rows
             default: launch_b3p_tile<AR, Tile<128, 128, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
         }
         return;
@@ -884,14 +887,14 @@ static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, boo
     if constexpr (AR < 4) {         // fp32 weights split on the fly: the bf16 arithmetics
         switch (tile) {
             case 1: launch_b3_tile<AR, T128x64>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
-            case 2: launch_b3_tile<AR, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
+            case 2: case 3: launch_b3_tile<AR, Tile<256, 64, 2, 2>>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
             default: launch_b3_tile<AR, T128x128>(a, trans_w, pro, residual, stats, relu, gln_bwd, st); break;
         }
     }
 }
 
 static void ctn_b3_launch_fwd(int ar, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
-    static const int d[3][2] = {{128, 128}, {128, 64}, {256, 64}};
+    static const int d[4][2] = {{128, 128}, {128, 64}, {256, 64}, {256, 64}};
     const int tile = ctn_b3_pick_tile(a, trans_w, pro, residual, stats, gln_bwd);
     a.tiles_r = ctn_cdiv(a.R, d[tile][0]);
     a.tiles_c = ctn_cdiv(a.Kp, d[tile][1]);

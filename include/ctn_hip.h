@@ -83,8 +83,8 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
                  void* workspace, size_t workspace_bytes, void* stream);
 size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
 /* Library switches (process-global; the library is driven by ONE host thread at a time: set them from that thread, between
- * steps -- workspace sizes and statistics layouts depend on them).  Keys: "arith" (below); "b3_tile" / "b3_tile_k3" 0|1|2 =
- * 128x128 / 128x64 / 256x64 tile of the split-bf16 forward / input-gradient kernels (the prologue + residual form has its
+ * steps -- workspace sizes and statistics layouts depend on them).  Keys: "arith" (below); "b3_tile" / "b3_tile_k3" 0|1|2|3 =
+ * 128x128 / 128x64 / 256x64 / 256x64 on 8 waves: tile of the split forward / input-gradient kernels (the prologue + residual form has its
  * own); "b3_wgrad_blocks", "wgrad_blocks": target workgroups per weight-gradient launch (split-bf16 / fp32 MFMA);
  * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE).  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);

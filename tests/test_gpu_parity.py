@@ -794,7 +794,7 @@ def _raw_pw_gemm(W, X, R, Cn, K, tw, residual=None):
     return out
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
 def test_b3_every_tile_and_weight_form(tile):
     """split-bf16 (b6) kernels: fp32 weights split on the fly (trans_w 0 / 1, pw_gemm_b3_kernel) and pre-split weight pieces
     (trans_w 2, pw_gemm_b3p_kernel) under every tile id, ragged rows / contraction / frames, against fp64 and bitwise
