@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Sustained energy per launch of the split-bf16 GEMM forms (one library per process: CTN_LIB_PATH, LABEL): each case loops for
-SECONDS_PER_CASE while benchmarks/power_lab_b6.sh samples `rocm-smi --showpower`.  FORMS="K1 K3 B1 B5 W1 W2", ARITH=b6|b3|fp32.
+SECONDS_PER_CASE while benchmarks/power_lab_b6.sh samples `rocm-smi --showpower`.  FORMS="K1 K3 B1 B5 W1 W2", ARITH=h3|b6|fp32.
 Prints 'case <name> <t_start> <t_end> <launches> <us_per_launch>' lines; timestamps are time.time()."""
 import os
 import sys

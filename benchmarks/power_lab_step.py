@@ -40,6 +40,6 @@ def case(name, fn):
 
 
 case("idle", lambda: time.sleep(0.01))
-for arith in ("b6", "fp32", "b3", "b6"):
+for arith in ("h3", "b6", "fp32", "h3"):
     ctn.set_gemm_arith(arith)
     case("training_step_" + arith, step)
