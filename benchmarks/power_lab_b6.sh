@@ -8,7 +8,7 @@ SP=$!
 for ar in ${ARITHS:-h3 b6 fp32}; do LABEL=$ar ARITH=$ar python benchmarks/power_lab_b6.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err; done
 for t in ${TILES:-}; do LABEL=b6_tile$t ARITH=b6 TILE=$t FORMS="K1 K3 B1 B5" python benchmarks/power_lab_b6.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err; done
 for tag in ${TAGS:-NK1 NOEPI NOMFMA NOA NOSPLIT NOLDSRD}; do
-  [ -f benchmarks/lab_b3_$tag.so ] && LABEL=b6_$tag ARITH=b6 CTN_LIB_PATH=benchmarks/lab_b3_$tag.so FORMS="${LABFORMS:-K1 B1}" python benchmarks/power_lab_b6.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err
+  [ -f benchmarks/lab_b3_$tag.so ] && LABEL=${LABARITH:-b6}_$tag ARITH=${LABARITH:-b6} CTN_LIB_PATH=benchmarks/lab_b3_$tag.so FORMS="${LABFORMS:-K1 B1}" python benchmarks/power_lab_b6.py >> gpurun_out/power_cases.txt 2>> gpurun_out/power_lab.err
 done
 kill $SP
 OUT=$OUT python - <<'PY'

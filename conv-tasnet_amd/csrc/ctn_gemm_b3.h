@@ -696,6 +696,7 @@ void pw_gemm_b3p_kernel(PwArgs a) {
         store_b(0, rb, rp);
         if (nk > 1) load_b(1, rb, rp);
         __syncthreads();
+        CTN_TL_STAMP(1);
         for (int kt = 0; kt < nk; ++kt) {
             compute(kt & 1, fa);
             if (kt + 1 < nk) { load_a(kt + 1, fa); store_b((kt + 1) & 1, rb, rp); }
