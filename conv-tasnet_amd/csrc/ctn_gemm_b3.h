@@ -870,7 +870,7 @@ static void ctn_b3_tile_dims(int* tm, int* tn) {    // the tile of every form th
 }
 // tile id of one launch: forms without a statistics epilogue may pick their own
 static int ctn_b3_pick_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool gln_bwd) {
-    if (trans_w == 2 && pro && residual && !stats && !gln_bwd && a.R <= 256 && a.R > 128) return g_ctn_b3_tile_k3;
+    if (trans_w == 2 && residual && !stats && !gln_bwd && a.R <= 256 && a.R > 128) return g_ctn_b3_tile_k3;      // K3 and B5
     return g_ctn_b3_tile;
 }
 
