@@ -2,7 +2,7 @@
 # benchmarks/lab_b3_<tag>.so   (the hooks are #ifdef CTN_EXP_B3_<tag> in csrc/ctn_gemm_b3.h; never defined in the product build)
 set -e
 cd "$(dirname "$0")/.."
-TAGS="${TAGS:-NK1 NOEPI NOMFMA NOA NOSPLIT NOLDSRD}"
+TAGS="${TAGS:-NK1 NOEPI NOMFMA NOA NOSPLIT NOLDSRD}"   # also: TIMELINE (benchmarks/b3_timeline.py, ws_timeline.py)
 mkdir -p /tmp/lab_objs
 HIPCC=/opt/rocm/bin/hipcc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form"

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""The wave-specialised GEMM kernel against the one-role kernel on every form at the paper shapes (M = 8: several tiles per
+workgroup and a partial last round): outputs must be bitwise equal, statistics partials equal to rounding."""
+import os
+import sys
+
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(here))
+sys.argv = [sys.argv[0], "K1", "0"]
+import torch  # noqa: E402
+src = open(os.path.join(here, "b3_only.py")).read().split("fn = fns[form]")[0]
+ns = {"__file__": os.path.join(here, "b3_only.py")}
+exec(compile(src, "b3_only_setup", "exec"), ns)
+ctn = ns["ctn"]
+outs = {"K1": ("outH", "part"), "K3": ("outB", "oam"), "B1": ("outH", "part"), "B5": ("outB", "oam")}
+bad = 0
+for blocks in (512,):
+    for form in ("K1", "K3", "B1", "B5"):
+        res = []
+        for ws in (0, 1):
+            ctn.lib.call("ctn_tune", b"b3_ws", ws)
+            ctn.lib.call("ctn_tune", b"b3_ws_blocks", blocks)
+            for n in outs[form]:
+                ns[n].zero_()
+            ns["fns"][form]()
+            torch.cuda.synchronize()
+            res.append([ns[n].clone() for n in outs[form]])
+        o0, o1 = res[0][0], res[1][0]
+        same = torch.equal(o0, o1)
+        nbad = int((o0 != o1).sum())
+        aux0, aux1 = res[0][1].double(), res[1][1].double()
+        auxerr = float((aux0 - aux1).abs().max() / (aux0.abs().max() + 1e-30))
+        print("blocks %4d %s: out bitwise %s (%d differ, max |d| %.3e, nan %d)  aux rel err %.3e" %
+              (blocks, form, same, nbad, float((o0 - o1).abs().max()), int(torch.isnan(o1).sum()), auxerr), flush=True)
+        if nbad:
+            idx = (o0 != o1).nonzero()
+            print("   first differing indices", idx[:4].tolist(), " last", idx[-2:].tolist())
+            import collections
+            tiles = collections.OrderedDict()
+            for m_, r_, c_ in idx.tolist():
+                tiles.setdefault((m_, r_ // 128, c_ // 64), []).append((r_ % 128, c_ % 64))
+            print("   %d bad tiles (m, rt, ct):" % len(tiles))
+            for k_, v_ in list(tiles.items())[:12]:
+                rows = sorted(set(r for r, c in v_)); cols = sorted(set(c for r, c in v_))
+                tr_ = o0.shape[1] // 128 if o0.shape[1] % 128 == 0 else 0
+                t_ = (k_[0] * 50 + k_[2]) * (o0.shape[1] // 128) + k_[1]
+                print("     tile %s t=%d (t %% 512 = %d, round %d): %d elements, rows %s cols %s" % (k_, t_, t_ % 512, t_ // 512, len(v_), rows, cols))
+            for q in idx[:2].tolist():
+                m, r, c = q
+                wrong, right = float(o1[m, r, c]), float(o0[m, r, c])
+                hits = (o0 == o1[m, r, c]).nonzero()[:4].tolist()
+                hits1 = (o1 == o1[m, r, c]).nonzero()[:4].tolist()
+                print("     [%d,%d,%d] right %.6g wrong %.6g ; wrong value found in reference at %s ; in ws output at %s" % (m, r, c, right, wrong, hits, hits1))
+            bad += 1
+print("FAILED" if bad else "OK")

@@ -32,7 +32,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     """Compile every .hip source for gfx950 and link libctn_hip.so next to this file."""
-    hdrs = [os.path.join(CSRC, h) for h in ("ctn_common.h", "ctn_gemm_common.h", "ctn_gemm_b3.h")]
+    hdrs = [os.path.join(CSRC, h) for h in ("ctn_common.h", "ctn_gemm_common.h", "ctn_gemm_b3.h", "ctn_gemm_ws.h")]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for s in SOURCES:

@@ -425,6 +425,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 }  // namespace
 
 #include "ctn_gemm_b3.h"            // the split-bf16 ("b3") arithmetic of the same GEMMs
+#include "ctn_gemm_ws.h"            // the wave-specialised h3 forward / input-gradient kernel
 
 int g_ctn_tile_override = -2;
 
@@ -659,6 +660,8 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "b3_tile") && value >= 0 && value <= 3) g_ctn_b3_tile = value;
     else if (!strcmp(key, "b3_tile_k3") && value >= 0 && value <= 3) g_ctn_b3_tile_k3 = value;
     else if (!strcmp(key, "b3_wgrad_blocks") && value >= 1) g_ctn_b3_wgrad_blocks = value;
+    else if (!strcmp(key, "b3_ws") && (value == 0 || value == 1)) g_ctn_b3_ws = value;
+    else if (!strcmp(key, "b3_ws_blocks") && value >= 1) g_ctn_b3_ws_blocks = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }
@@ -769,7 +772,8 @@ int ctn_pw_gemm_h3(const void* Wp, const float* X, float* Out, int M, int R, int
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out;
     a.residual = residual; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
     a.x_amax = x_amax; a.pro_gbmax = pro_gbmax; a.out_amax = out_amax;
-    ctn_b3_launch_fwd(4, a, 2, pro_part != nullptr, residual != nullptr, epi_part != nullptr, false, false, (hipStream_t)stream);
+    if (!ctn_ws_launch(a, pro_part != nullptr, residual != nullptr, epi_part != nullptr, false, false, (hipStream_t)stream))
+        ctn_b3_launch_fwd(4, a, 2, pro_part != nullptr, residual != nullptr, epi_part != nullptr, false, false, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_gemm_h3");
     return CTN_OK;
 }
@@ -785,7 +789,8 @@ int ctn_pw_dgrad_gln_h3(const void* Wp, const float* dOut, float* dN, int M, int
     a.W = (const float*)Wp; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
     a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
     a.x_amax = g_amax;
-    ctn_b3_launch_fwd(4, a, 2, false, false, false, false, true, (hipStream_t)stream);
+    if (!ctn_ws_launch(a, false, false, false, false, true, (hipStream_t)stream))
+        ctn_b3_launch_fwd(4, a, 2, false, false, false, false, true, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln_h3");
     return CTN_OK;
 }

@@ -195,7 +195,13 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     s1 += (t0 + t1) + (t2 + t3);
                     s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, f32x4v{v.x, v.y, v.z, v.w}), rsOut, vo0, so, 0);
+                // The pass offset rides in the per-lane offset, not in an SGPR soffset.  hipcc (ROCm 7.2) takes a 16-byte buffer
+                // store with a REGISTER soffset to need no wait state before a VALU write of its data registers and may schedule
+                // one right behind it (40 such pairs in the round-3 listings of these epilogues, e.g. buffer_store_dwordx4 v[2:5]
+                // .. s4 offen ; v_cvt_f64_f32 v[2:3]); on gfx950 the store can then pick up the NEW value in part of its lanes when
+                // the CU is busy (observed in round 4 on pw_gemm_ws_kernel: 16 of 8192 outputs of a tile, profiles/README.md
+                // r04_a).  With a zero soffset the compiler's hazard recogniser inserts the wait states itself.
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, f32x4v{v.x, v.y, v.z, v.w}), rsOut, vo0 + so, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -86,7 +86,9 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * steps -- workspace sizes and statistics layouts depend on them).  Keys: "arith" (below); "b3_tile" / "b3_tile_k3" 0|1|2|3 =
  * 128x128 / 128x64 / 256x64 / 256x64 on 8 waves: tile of the split forward / input-gradient kernels (the prologue + residual form has its
  * own); "b3_wgrad_blocks", "wgrad_blocks": target workgroups per weight-gradient launch (split-bf16 / fp32 MFMA);
- * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE).  Defaults are the measured best. */
+ * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE); "b3_ws" 0|1 (default 0): run the h3 forward /
+ * input-gradient GEMMs on the wave-specialised persistent kernel (csrc/ctn_gemm_ws.h; same values, measured slower: kept as a tested
+ * experiment), "b3_ws_blocks": its workgroup count.  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
  *   3 = "h3" (default): the GEMMs of the composite stacks (ctn_tcn_*) run on the ctn_*_h3 entry points below -- two fp16 pieces

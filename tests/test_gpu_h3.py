@@ -148,6 +148,55 @@ def test_h3_gemm_forms_against_fp64(scenario, M, B, H, K):
           lambda: ops.pw_wgrad(gB, xH, B, H, K, pro=(gam, bet, a, ms)), refw2, scw2)
 
 
+@pytest.mark.parametrize("blocks", [512, 100])
+def test_wave_specialised_kernel_equals_the_one_role_kernel(blocks):
+    """pw_gemm_ws_kernel (csrc/ctn_gemm_ws.h; opt-in: ctn_tune("b3_ws", 1)) against the product kernel on the four forward /
+    input-gradient forms at the paper shapes with M = 8 -- several tiles per persistent workgroup, a partial last round, two
+    workgroups per CU (512) or one (100): outputs bitwise equal (same MFMA order per accumulator), tracked maxima equal,
+    statistics partials equal to rounding (they are summed in another fixed order).  This is the case that exposed the
+    store-data hazard of 16-byte buffer stores with a register soffset (csrc/ctn_gemm_common.h)."""
+    M, B, H, K = 8, 256, 512, 3199
+    Kp = ops.padded_frames(K)
+    xB, xH = (pad(torch.randn(M, c, K, generator=g(i)), Kp).to(DEV) for i, c in ((1, B), (2, H)))
+    w1, w2 = (torch.randn(H, B, generator=g(5)) * 0.05).to(DEV), (torch.randn(B, H, generator=g(6)) * 0.05).to(DEV)
+    a = torch.full((1,), 0.25, device=DEV)
+    gam, bet = torch.randn(1, H, 1, generator=g(7)).to(DEV), torch.randn(1, H, 1, generator=g(8)).to(DEV)
+    ms = torch.tensor([[0.1, 1.3]] * M, device=DEV)
+    pre = torch.where(xH >= 0, xH, 0.25 * xH).double()
+    st2 = torch.stack([pre[..., :K].sum((1, 2)), (pre[..., :K] ** 2).sum((1, 2))], -1).reshape(M, 1, 2).contiguous()
+    p1, p2 = ops.h3_pieces(w1, H, B, False), ops.h3_pieces(w2, B, H, False)
+    q2, q1 = ops.h3_pieces(w2, H, B, True), ops.h3_pieces(w1, B, H, True)
+    axB, axH, gbm = ops.absmax_rows(xB), ops.absmax_rows(xH), ops.absmax_of(gam, bet)
+
+    def forms():
+        oam3 = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+        oam5 = torch.zeros(M, ops.AMAX_SLOTS, dtype=torch.int32, device=DEV)
+        ms_out = torch.empty(M, 2, device=DEV)
+        k1, k1p = ops.pw_gemm_h3(p1, xB, H, B, K, axB, epi_alpha=a)
+        k3, _ = ops.pw_gemm_h3(p2, xH, B, H, K, axH, pro=(st2, gam, bet, a), gbmax=gbm, residual=xB, ms_out=ms_out, out_amax=oam3)
+        b1, b1p = ops.pw_dgrad_gln_h3(q2, xB, H, B, K, xH, gam, a, ms, axB)
+        b5, _ = ops.pw_gemm_h3(q1, xH, B, H, K, axH, residual=xB, out_amax=oam5)
+        torch.cuda.synchronize()
+        return (k1, k3, b1, b5), (k1p.sum(1), b1p.sum(1), ms_out), (amax_f(oam3), amax_f(oam5))
+
+    try:
+        ctn.lib.call("ctn_tune", b"b3_ws", 0)
+        ref = forms()
+        ctn.lib.call("ctn_tune", b"b3_ws", 1)
+        ctn.lib.call("ctn_tune", b"b3_ws_blocks", blocks)
+        for _ in range(3):                  # (the hazard was intermittent)
+            got = forms()
+            for name, x, y in zip(("K1", "K3", "B1", "B5"), ref[0], got[0]):
+                assert torch.equal(x, y), "%s: %d outputs differ" % (name, int((x != y).sum()))
+            for x, y in zip(ref[1], got[1]):
+                assert torch.allclose(x, y, rtol=1e-6, atol=1e-6 * float(x.abs().max()))
+            for x, y in zip(ref[2], got[2]):
+                assert torch.equal(x, y)
+    finally:
+        ctn.lib.call("ctn_tune", b"b3_ws", 0)
+        ctn.lib.call("ctn_tune", b"b3_ws_blocks", 512)
+
+
 def test_h3_producers_track_exact_maxima():
     """ctn_dw_fwd (statistics epilogue) and ctn_gln_prelu_bwd write the maximum of what they store, per utterance."""
     M, H, K = 3, 132, 700
