@@ -37,6 +37,11 @@ ARITH = {"name": "h3"}         # GEMM arithmetic of this run (--arith): "h3" (li
                                # fp32 operand under tracked power-of-two scales, 3 f16 MFMAs per product step (fp32-faithful products; every
                                # other GEMM as b6), "b6" = three bf16 pieces, 6 bf16 MFMAs (fp32-faithful), "fp32" = fp32 MFMA
 ARITH_IDS = {"fp32": 0, "b6": 2, "h3": 3}
+# `dtype` of the JSON line: the arithmetic type the path computes in (not a precision claim: tests/test_gpu_h3.py holds those)
+DTYPE_TEXT = {"h3": "f32 (1x1-conv GEMMs of the stacks as h3: two fp16 pieces per f32 operand under tracked power-of-two scales, three "
+                    "f16 MFMAs, f32 accumulate; other GEMMs b6: three bf16 pieces, six bf16 MFMAs; everything else f32, statistics f64)",
+              "b6": "f32 (1x1-conv GEMMs as b6: three bf16 pieces per f32 operand, six bf16 MFMAs, f32 accumulate; everything else f32, statistics f64)",
+              "fp32": "f32 (f32 MFMA, bit-exact f32 FMA chains; statistics f64)"}
 MFMA_PER_STEP = {"b6": 6, "h3": 3}
 PER_GPU_BATCH = 8
 CONFIGS = {
@@ -104,12 +109,12 @@ def _host_cpu():
     return model, max(n, 1), ", ".join("%s=%d" % kv for kv in limits.items())
 
 
-def cpu_baseline(cfg, budget_s=150.0):
+def cpu_baseline(cfg, budget_s=240.0):
     """The oracle (torch CPU restatement of the reference step: fwd + loss + bwd + clip(5) + Adam) on this host, batch 8,
-    all physical cores this process may use; then the same on 8 threads (the survey container's count).  BASELINE.md section 4
-    asks for warm-up + >= 10 timed steps, median and min; a paper-config step takes ~20 s on a 1-GPU box's 16-core share, so the
-    sample is bounded: the first call is a warm-up (more while steps are short), then timed steps until 10 are in, or until at
-    least 5 (3 when a step exceeds 25 s) are in and the wall budget is spent."""
+    all physical cores this process may use; then the same on 8 threads (the survey container's count).  BASELINE.md section 4:
+    3 warm-up + >= 10 timed steps, median and min.  A paper-config step takes ~20 s on a 1-GPU box's 16-core share, so the
+    sample is bounded in wall time: 3 warm-up steps (2 when a step exceeds 25 s), then timed steps until 10 are in, or until at
+    least 5 are in and the wall budget is spent."""
     from oracle import ctn_oracle as O
     ocfg = O.Config(norm_type=cfg["norm_type"], causal=cfg["causal"], **cfg["model"])
     model, cores, how = _host_cpu()
@@ -124,12 +129,11 @@ def cpu_baseline(cfg, budget_s=150.0):
             O.train_step(ocfg, sd, state, mix, src, lens)
             dt = time.perf_counter() - t0
             elapsed = time.perf_counter() - t_start
-            if warm < max_warm and (warm == 0 or dt < 2.0):
-                warm += 1                      # the first call always is a warm-up (allocator, thread pool)
+            if warm < (max_warm if dt <= 25.0 else min(max_warm, 2)):
+                warm += 1                      # allocator, thread pool, first-touch of 18 GB of saved activations
                 continue
             times.append(dt)
-            need = min_steps if dt <= 25.0 else min(min_steps, 3)
-            if len(times) >= max_steps or (len(times) >= need and elapsed + dt > budget):
+            if len(times) >= max_steps or (len(times) >= min_steps and elapsed + dt > budget):
                 return warm, times
 
     warm, times = run(cores, budget_s, 3, 5, 10)
@@ -144,7 +148,7 @@ def cpu_baseline(cfg, budget_s=150.0):
                      "value = batch / median step time"
                      % (len(times), PER_GPU_BATCH, warm, cores, budget_s)}
     if cores != 8:
-        w8, t8 = run(min(8, cores), budget_s * 0.3, 1, 2, 3)
+        w8, t8 = run(min(8, cores), budget_s * 0.2, 1, 2, 3)
         out["threads8"] = {"value": round(PER_GPU_BATCH / statistics.median(t8), 4), "timed_steps": len(t8), "warmup_steps": w8,
                            "threads": min(8, cores), "min_s_per_step": round(min(t8), 3)}
     return out
@@ -314,8 +318,8 @@ def roofline(rows, probe_steps, ms_per_step, fused_min_bytes):
                     "and utterance) and executed MFMA FLOPs of one step over the timed ms_per_step and the peaks"}
     traffic, src = None, None
     for pmc in sorted(os.listdir(os.path.join(ROOT, "profiles"))):      # PMC passes (benchmarks/pmc_traffic.sh): family + arithmetic must match
-        if not (pmc.startswith("r03_pmc_") and pmc.endswith(".json")):
-            continue
+        if not (len(pmc) > 8 and pmc[0] == "r" and pmc[1:3].isdigit() and pmc[3:8] == "_pmc_" and pmc.endswith(".json")):
+            continue                                    # r<round>_pmc_*.json, sorted: the latest round's pass wins
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", pmc)))
             if j.get("family", "")[:2] == dom["family"][:2] and j.get("arith", "fp32") in (ARITH["name"], "any"):
@@ -345,6 +349,7 @@ def main():
                          "three f16 MFMAs per product step (fp32-faithful products; library default), b6 = three bf16 pieces per fp32 "
                          "operand, six bf16 MFMAs (fp32-faithful), fp32 = fp32-MFMA kernels")
     ap.add_argument("--no-side-arith", action="store_true", help="skip the short runs on the other arithmetics after the timed region")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the short side records (causal, c3, inference, streaming) after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CTN_BENCH_GRAPH", "0")),
@@ -384,6 +389,8 @@ def main():
         from conv_tasnet_amd.graphed import GraphedBackprop
         graphed = GraphedBackprop(model, opt, (mix, lens, src))
 
+    AR_PROBE = None
+
     def step():
         if graphed is not None:
             loss = graphed(mix, lens, src)
@@ -392,7 +399,14 @@ def main():
             est = model(mix)
             loss, _, _, _ = ctn.cal_loss(src, est, lens)
             loss.backward()
-        scale = parallel.allreduce_gradients(opt)
+        if AR_PROBE is not None and world > 1:      # roofline leg: the exposed part of the gradient all-reduce (what the step waits for)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            scale = parallel.allreduce_gradients(opt)
+            e1.record()
+            AR_PROBE.append((e0, e1))
+        else:
+            scale = parallel.allreduce_gradients(opt)
         opt.step(max_grad_norm=5.0, grad_scale=scale)
         loss_acc.add_(loss.detach())
 
@@ -427,7 +441,7 @@ def main():
             "metric": "4s 8kHz 2-spk utterances/sec (fwd+bwd)", "value": round(value, 2), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE_TEXT[args.arith],
             "gemm_arith": args.arith, "data": "synthetic",
             "config": {"workload": (cfg["name"] % PER_GPU_BATCH) + " utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam",
                        "global_batch": PER_GPU_BATCH * world, "samples_per_utterance": cfg["T"],
@@ -490,9 +504,12 @@ def main():
         torch.cuda.synchronize()
         ctn.lib.probe = []
         ctn.lib.call("ctn_probe_enable", 1)
+        AR_PROBE = []
         for _ in range(probe_steps):
             step()
         torch.cuda.synchronize()
+        ar_us = [1e3 * a.elapsed_time(b) for a, b in AR_PROBE]
+        AR_PROBE = None
         cap = 4096 * probe_steps
         fam_ids, fam_us = (ctypes.c_int * cap)(), (ctypes.c_float * cap)()
         n = ctn.lib.load().ctn_probe_read(fam_ids, fam_us, cap)
@@ -502,6 +519,146 @@ def main():
             c = cfg["model"]
             fused_min = PER_GPU_BATCH * c["X"] * c["R"] * 4.0 * K * ((3 * c["B"] + 4 * c["H"]) + (3 * c["B"] + 9 * c["H"]))
             out["roofline"] = roofline(family_table(probe, stack, cfg, K, probe_steps), probe_steps, out["ms_per_step"], fused_min)
+            if ar_us:
+                out["roofline"]["gradient_allreduce"] = {
+                    "bytes_per_step": int(opt.flat_grads.numel()) * 4, "exposed_us_per_step": round(sum(ar_us) / len(ar_us), 1),
+                    "note": "time the main stream spends in allreduce_gradients() behind the backward pass: the buckets issued "
+                            "during it (parallel.GradientBuckets) are waited for here, the front / back-end remainder is reduced here"}
+    if rank == 0 and "roofline" in out:
+        # executed f16 / bf16 MFMA FLOPs from the per-family table (stack GEMMs at 3 MFMAs per product under h3, the front / back
+        # end at b6's 6) instead of 3 x all model FLOPs
+        st = out["roofline"]["step"]
+        if args.arith != "fp32":
+            out["executed_mfma_frac_of_bf16_peak"] = st["bf16_mfma_frac"]          # rank 0's FLOPs over the step and one GPU's peak
+            out["executed_mfma_frac_source"] = "roofline.families (per-family executed MFMA FLOPs over the timed step)"
+
+    # ---- side records: the other BASELINE configs and the inference callers, short runs in the same process (every rank takes
+    # part: the training records contain the gradient all-reduce) -------------------------------------------------------------
+    if not args.no_side_configs and graphed is None and args.config == "paper":
+        def sync_time(fn, n):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([d], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t)
+            return d
+
+        def side_config(name, warm=5, nsteps=10):
+            c2 = CONFIGS[name]
+            torch.manual_seed(0)
+            m2 = ctn.ConvTasNet(**c2["model"], norm_type=c2["norm_type"], causal=c2["causal"], mask_nonlinear="relu").to(device)
+            o2 = FlatAdam(m2.parameters(), lr=1e-3)
+            parallel.broadcast_parameters(o2.flat_params)
+            parallel.enable_overlap(o2, c2["model"]["X"])
+            mx, ln, sr = next(iter(SyntheticLoader(1, 8, samples=c2["T"], C=c2["model"]["C"], sample_rate=c2["sr"], rank=rank, world=world)))
+            mx, ln, sr = mx.to(device), ln.to(device), sr.to(device)
+
+            def st2():
+                o2.zero_grad()
+                ctn.cal_loss(sr, m2(mx), ln)[0].backward()
+                o2.step(max_grad_norm=5.0, grad_scale=parallel.allreduce_gradients(o2))
+            for _ in range(warm):
+                st2()
+            d = sync_time(st2, nsteps)
+            f2, K2 = flops_fwd(c2["model"], c2["T"])
+            rec = {"workload": (c2["name"] % 8) + " utterances per GPU, fwd+PIT-loss+bwd+clip(5)+Adam", "value": round(8 * world * nsteps / d, 2),
+                   "unit": "utterances/sec", "ms_per_step": round(1e3 * d / nsteps, 3), "steps": nsteps, "warmup": warm, "gemm_arith": args.arith,
+                   "hbm_frac_of_fused_minimum": round(8 * c2["model"]["X"] * c2["model"]["R"] * 4.0 * K2 * ((3 * c2["model"]["B"] + 4 * c2["model"]["H"]) + (3 * c2["model"]["B"] + 9 * c2["model"]["H"]))
+                                                      / (d / nsteps) / (PEAK_HBM_GBS * 1e9), 4)}
+            return rec, m2, o2
+
+        side_cfg = {}
+        rec, m_c, o_c = side_config("causal")
+        # streaming causal inference (src/conv_tasnet.py:182,257-266 -- the reason the causal variant exists; conv_tasnet_amd/streaming.py):
+        # one utterance, 100-ms chunks, carried depthwise / encoder / overlap-add state; real-time factor = processing time / audio time
+        from conv_tasnet_amd.streaming import StreamingSeparator
+        chunk = 800
+        sep = StreamingSeparator(m_c.eval(), batch=1)
+        audio = torch.randn(1, 40 * chunk, device=device) * 0.1
+        with torch.no_grad():
+            for i in range(5):
+                sep.push(audio[:, i * chunk:(i + 1) * chunk])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(40):
+                sep.push(audio[:, i * chunk:(i + 1) * chunk])
+            torch.cuda.synchronize()
+            dstream = time.perf_counter() - t0
+        rec["streaming_inference"] = {"chunk_samples": chunk, "chunk_ms": 100.0, "batch": 1, "chunks": 40, "ms_per_chunk": round(1e3 * dstream / 40, 3),
+                                      "real_time_factor": round(dstream / (40 * chunk / 8000.0), 5),
+                                      "note": "StreamingSeparator.push on the causal cLN model, exact chunk-wise inference with carried state; "
+                                              "host-bound (per-kernel Python path, ~230 launches per chunk)"}
+        side_cfg["causal"] = rec
+        del sep, m_c, o_c
+        rec, m_3, o_3 = side_config("c3")
+        side_cfg["c3"] = rec
+        del m_3, o_3
+        torch.cuda.empty_cache()
+        parallel.enable_overlap(opt, cfg["model"]["X"])
+        # forward-only throughput of configs[1] (separate.py / evaluate.py: model(mixture) under no_grad -> the stack's forward
+        # composite without saved activations), and its dominant kernel family
+        model.eval()
+        with torch.no_grad():
+            def fwd():
+                model(mix)
+            for _ in range(5):
+                fwd()
+            ninf = 20
+            dinf = sync_time(fwd, ninf)
+            inf = {"workload": (cfg["name"] % PER_GPU_BATCH) + " utterances per GPU, forward only (torch.no_grad)", "value": round(PER_GPU_BATCH * world * ninf / dinf, 2),
+                   "unit": "utterances/sec", "ms_per_forward": round(1e3 * dinf / ninf, 3), "passes": ninf, "warmup": 5, "gemm_arith": args.arith}
+            import ctypes
+            fwd()
+            torch.cuda.synchronize()
+            ctn.lib.probe = []
+            ctn.lib.call("ctn_probe_enable", 1)
+            for _ in range(3):
+                fwd()
+            torch.cuda.synchronize()
+            cap = 4096 * 3
+            fam_ids, fam_us = (ctypes.c_int * cap)(), (ctypes.c_float * cap)()
+            n = ctn.lib.load().ctn_probe_read(fam_ids, fam_us, cap)
+            probe, ctn.lib.probe = ctn.lib.probe, None
+        model.train()
+        if rank == 0:
+            ffwd, K = flops_fwd(cfg["model"], cfg["T"])
+            c = cfg["model"]
+            rows = family_table(probe, [(int(fam_ids[i]), float(fam_us[i])) for i in range(min(n, cap))], cfg, K, 3)
+            dom = rows[0]
+            fwd_min = PER_GPU_BATCH * c["X"] * c["R"] * 4.0 * K * (3 * c["B"] + 4 * c["H"])
+            tfw = dinf / ninf
+            inf["roofline"] = {"kernel": dom["family"], "bound": dom["bound"], "achieved": dom.get("achieved"), "peak": dom.get("peak"), "unit": dom.get("unit"),
+                               "frac": dom.get("frac"), "us_per_launch": dom["us_per_launch"], "launches_per_pass": dom["launches_per_step"],
+                               "step": {"fused_minimum_bytes": fwd_min, "hbm_frac_of_fused_minimum": round(fwd_min / tfw / (PEAK_HBM_GBS * 1e9), 4),
+                                        "executed_f16_mfma_frac": round(sum(r.get("executed_mfma_flops_per_step", 0.0) for r in rows if r.get("on_bf16_mfma")) / tfw / (PEAK_BF16_MFMA_TFLOPS * 1e12), 4)},
+                               "families": [{k: r[k] for k in ("family", "bound", "launches_per_step", "us_per_launch", "ms_per_step", "frac") if k in r} for r in rows[:6]]}
+            out["inference"] = inf
+            out["other_configs"] = side_cfg
+
+    if world > 1:
+        # what the collective library saw: backend, ranks, one device per rank (RCCL == torch's "nccl" backend on ROCm)
+        info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": torch.cuda.current_device(),
+                "device_name": torch.cuda.get_device_name(), "pid": os.getpid()}
+        try:
+            info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # gloo rehearsal builds
+            info["nccl_version"] = "n/a (%s)" % type(e).__name__
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info)
+        if rank == 0:
+            out["distributed"] = {"backend": info["backend"], "rccl_ranks": info["world_size"], "nccl_version": info["nccl_version"],
+                                  "ranks": [{k: g[k] for k in ("device", "device_name", "pid")} for g in gathered],
+                                  "gradient_allreduce_bytes_per_step": int(opt.flat_grads.numel()) * 4,
+                                  "buckets": "one per repeat (X blocks) issued during the backward pass + remainder" if getattr(opt, "_ctn_buckets", None) is not None else "one collective after the backward pass"}
     # the process group is finished BEFORE the CPU leg: the other ranks must not sit in a collective (or hold the GPUs) while
     # rank 0 spends minutes on the host cores
     if world > 1:

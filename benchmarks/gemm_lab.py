@@ -13,9 +13,9 @@ seconds = float(os.environ.get("SECONDS_PER_CASE", "1.0"))
 settings = [a for a in sys.argv[1:] if "=" in a] or ["b3_tpw=1"]
 sys.argv = [sys.argv[0], "K1", "0"]
 import torch  # noqa: E402
-src = open(os.path.join(here, "b3_only.py")).read().split("fn = fns[form]")[0]
-ns = {"__file__": os.path.join(here, "b3_only.py")}
-exec(compile(src, "b3_only_setup", "exec"), ns)
+src = open(os.path.join(here, "gemm_only.py")).read().split("fn = fns[form]")[0]
+ns = {"__file__": os.path.join(here, "gemm_only.py")}
+exec(compile(src, "gemm_only_setup", "exec"), ns)
 ctn = ns["ctn"]
 print("arith", ctn.gemm_arith(), "lib", ctn.LIB_PATH, flush=True)
 for setting in settings:

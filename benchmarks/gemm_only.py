@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One GEMM form of the composite stacks launched N times at the paper shapes (for rocprofv3 / PMC passes), under the library's
-arithmetic (CTN_GEMM_ARITH; h3 = the ctn_*_h3 entry points).  usage: b3_only.py K1|K3|B1|B5|W1|W2 [n]"""
+arithmetic (CTN_GEMM_ARITH; h3 = the ctn_*_h3 entry points).  usage: gemm_only.py K1|K3|B1|B5|W1|W2 [n]"""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-workgroup phase timeline of one split-bf16 GEMM form (needs a library built with -DCTN_EXP_B3_TIMELINE:
-CTN_LIB_PATH=benchmarks/lab_b3_TIMELINE.so).  Stamps: 0 entry, 1 first k-tile staged, 2 main loop done, 3 epilogue done;
-s_memrealtime ticks are 10 ns, s_memtime counts shader cycles.  usage: b3_timeline.py K1|K3|B1|B5 [warm launches]"""
+CTN_LIB_PATH=benchmarks/lab_gemm_TIMELINE.so).  Stamps: 0 entry, 1 first k-tile staged, 2 main loop done, 3 epilogue done;
+s_memrealtime ticks are 10 ns, s_memtime counts shader cycles.  usage: gemm_timeline.py K1|K3|B1|B5 [warm launches]"""
 import ctypes
 import os
 import subprocess
@@ -17,9 +17,9 @@ saved = sys.argv
 sys.argv = [saved[0], form, "0"]
 import torch  # noqa: E402
 import conv_tasnet_amd as ctn  # noqa: E402
-src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "b3_only.py")).read().split("fn = fns[form]")[0]
-ns = {"__file__": os.path.join(os.path.dirname(os.path.abspath(__file__)), "b3_only.py")}
-exec(compile(src, "b3_only_setup", "exec"), ns)
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_only.py")).read().split("fn = fns[form]")[0]
+ns = {"__file__": os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_only.py")}
+exec(compile(src, "gemm_only_setup", "exec"), ns)
 fn = ns["fns"][form]
 for _ in range(warm):
     fn()

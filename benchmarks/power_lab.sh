@@ -6,7 +6,7 @@ MODE=${1:-kernels}
 SP=$!
 if [ "$MODE" = mfma ]; then ./benchmarks/mfma_probe.bin 5 > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
 elif [ "$MODE" = step ]; then python benchmarks/power_lab_step.py > gpurun_out/power_cases.txt 2> gpurun_out/power_lab.err
-else echo "usage: power_lab.sh mfma|step   (per-kernel energies: benchmarks/power_lab_b6.sh)"; kill $SP; exit 1; fi
+else echo "usage: power_lab.sh mfma|step   (per-kernel energies: benchmarks/power_lab_gemm.sh)"; kill $SP; exit 1; fi
 kill $SP
 export MODE
 python - <<'PY'

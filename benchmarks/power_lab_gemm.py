@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Sustained energy per launch of the split-bf16 GEMM forms (one library per process: CTN_LIB_PATH, LABEL): each case loops for
-SECONDS_PER_CASE while benchmarks/power_lab_b6.sh samples `rocm-smi --showpower`.  FORMS="K1 K3 B1 B5 W1 W2", ARITH=h3|b6|fp32.
+SECONDS_PER_CASE while benchmarks/power_lab_gemm.sh samples `rocm-smi --showpower`.  FORMS="K1 K3 B1 B5 W1 W2", ARITH=h3|b6|fp32.
 Prints 'case <name> <t_start> <t_end> <launches> <us_per_launch>' lines; timestamps are time.time()."""
 import os
 import sys
@@ -15,8 +15,8 @@ if os.environ.get("ARITH"):
     os.environ["CTN_GEMM_ARITH"] = os.environ["ARITH"]
 sys.argv = [sys.argv[0], "K1", "0"]
 import torch  # noqa: E402
-src = open(os.path.join(here, "b3_only.py")).read().split("fn = fns[form]")[0]
-ns = {"__file__": os.path.join(here, "b3_only.py")}
+src = open(os.path.join(here, "gemm_only.py")).read().split("fn = fns[form]")[0]
+ns = {"__file__": os.path.join(here, "gemm_only.py")}
 if os.environ.get("ARITH") == "fp32":       # the fp32-MFMA kernels take the stored matrices, not pieces
     src = src.replace("p1, p2 = _b3_pieces(w1, H, B, False), _b3_pieces(w2, B, H, False)", "p1, p2 = w1, w2")
     src = src.replace("q2, q1 = _b3_pieces(w2, H, B, True), _b3_pieces(w1, B, H, True)", "q2, q1 = w2, w1")
@@ -28,7 +28,7 @@ if os.environ.get("TILE"):                  # tile id of the split-bf16 forward 
     import conv_tasnet_amd as _ctn
     _ctn.lib.call("ctn_tune", b"b3_tile", int(os.environ["TILE"]))
     _ctn.lib.call("ctn_tune", b"b3_tile_k3", int(os.environ["TILE"]))
-exec(compile(src, "b3_only_setup", "exec"), ns)
+exec(compile(src, "gemm_only_setup", "exec"), ns)
 time.sleep(0.5)
 for form in forms:
     fn = ns["fns"][form]

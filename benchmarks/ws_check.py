@@ -8,9 +8,9 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(here))
 sys.argv = [sys.argv[0], "K1", "0"]
 import torch  # noqa: E402
-src = open(os.path.join(here, "b3_only.py")).read().split("fn = fns[form]")[0]
-ns = {"__file__": os.path.join(here, "b3_only.py")}
-exec(compile(src, "b3_only_setup", "exec"), ns)
+src = open(os.path.join(here, "gemm_only.py")).read().split("fn = fns[form]")[0]
+ns = {"__file__": os.path.join(here, "gemm_only.py")}
+exec(compile(src, "gemm_only_setup", "exec"), ns)
 ctn = ns["ctn"]
 outs = {"K1": ("outH", "part"), "K3": ("outB", "oam"), "B1": ("outH", "part"), "B5": ("outB", "oam")}
 bad = 0

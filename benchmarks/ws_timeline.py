@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the two roles of pw_gemm_ws_kernel spend their cycles (needs a library built with -DCTN_EXP_B3_TIMELINE:
-CTN_LIB_PATH=benchmarks/lab_b3_TIMELINE.so).  Per workgroup: cycles of the MFMA role (wave 0) in total / waiting at barriers /
+CTN_LIB_PATH=benchmarks/lab_gemm_TIMELINE.so).  Per workgroup: cycles of the MFMA role (wave 0) in total / waiting at barriers /
 writing patches, cycles of the IO role (wave 4) in total / waiting at barriers.  usage: ws_timeline.py K1|K3|B1|B5 [blocks]"""
 import ctypes
 import os
@@ -14,9 +14,9 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(here))
 sys.argv = [sys.argv[0], form, "0"]
 import torch  # noqa: E402
-src = open(os.path.join(here, "b3_only.py")).read().split("fn = fns[form]")[0]
-ns = {"__file__": os.path.join(here, "b3_only.py")}
-exec(compile(src, "b3_only_setup", "exec"), ns)
+src = open(os.path.join(here, "gemm_only.py")).read().split("fn = fns[form]")[0]
+ns = {"__file__": os.path.join(here, "gemm_only.py")}
+exec(compile(src, "gemm_only_setup", "exec"), ns)
 ctn = ns["ctn"]
 ctn.lib.call("ctn_tune", b"b3_ws_blocks", blocks)
 fn = ns["fns"][form]

@@ -8,7 +8,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ctn_hip.h")
-# CTN_LIB_PATH: an alternative build of the same ABI (benchmarks/b3_lab_build.sh: phase-ablation builds)
+# CTN_LIB_PATH: an alternative build of the same ABI (benchmarks/gemm_ablate_build.sh: phase-ablation builds)
 LIB_PATH = os.environ.get("CTN_LIB_PATH") or os.path.join(_HERE, "libctn_hip.so")
 
 _SCALARS = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float,

@@ -12,6 +12,7 @@
 // call ends by ordering `stream` after `side_stream`, so every gradient is complete in stream order when it returns.
 #include "ctn_common.h"
 #include "../../include/ctn_hip.h"
+#include <mutex>
 #include <vector>
 
 
@@ -21,7 +22,8 @@
 enum { F_K1 = 0, F_K2, F_K3, F_B1, F_B2, F_B3, F_B4, F_B5, F_B6, F_FIN, F_PREP, F_CLN_FWD, F_CLN_BWD, F_TAPS, F_COUNT };
 namespace {
 struct ProbeRec { int fam; hipEvent_t e0, e1; };
-std::vector<ProbeRec> g_probe;
+std::vector<ProbeRec> g_probe;          // guarded by g_probe_mu: a second host thread that drives the library while a recording is
+std::mutex g_probe_mu;                  // on appends its launch groups too (they are attributed by family, not by thread)
 bool g_probe_on = false;
 struct ProbeMark {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -35,6 +37,7 @@ struct ProbeMark {
     ~ProbeMark() {
         if (e0 == nullptr) return;
         hipEventRecord(e1, st);
+        std::lock_guard<std::mutex> lk(g_probe_mu);
         g_probe.push_back(ProbeRec{fam, e0, e1});
     }
 };
@@ -42,6 +45,7 @@ struct ProbeMark {
 #define PROBED(fam, stream, expr) [&]() -> int { ProbeMark pm_(fam, stream); return (expr); }()
 
 extern "C" int ctn_probe_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
     for (ProbeRec& r : g_probe) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     g_probe.clear();
     g_probe_on = on != 0;
@@ -49,6 +53,7 @@ extern "C" int ctn_probe_enable(int on) {
 }
 
 extern "C" int ctn_probe_read(int* fam, float* us, int cap) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
     int n = 0;
     for (ProbeRec& r : g_probe) {
         float ms = 0.f;

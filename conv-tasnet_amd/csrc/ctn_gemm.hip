@@ -438,7 +438,16 @@ static int g_arith = -1;
 static int arith_id() {
     if (g_arith < 0) {
         const char* e = getenv("CTN_GEMM_ARITH");
-        g_arith = (e && !strcmp(e, "fp32")) ? 0 : (e && !strcmp(e, "b6")) ? 2 : 3;
+        if (!e || !*e || !strcmp(e, "h3")) g_arith = 3;
+        else if (!strcmp(e, "b6")) g_arith = 2;
+        else if (!strcmp(e, "fp32")) g_arith = 0;
+        else {
+            // an unknown value (round 2's "b3", a typo such as "FP32") must not silently select an arithmetic the caller did not
+            // ask for: say so once and run the bit-exact one
+            fprintf(stderr, "libctn_hip: CTN_GEMM_ARITH=%s is not one of h3|b6|fp32 -- using fp32 (bit-exact fp32 MFMA)\n", e);
+            ctn_set_error("CTN_GEMM_ARITH=%s is not one of h3|b6|fp32: fp32 selected", e);
+            g_arith = 0;
+        }
     }
     return g_arith;
 }

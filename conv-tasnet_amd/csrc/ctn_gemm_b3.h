@@ -2,14 +2,23 @@
 //
 //   "h3" (library default for the composite stacks; template id AR = 5, A/B builds 4):
 //     a s = a0 + a1 + r,  a0 = fp16_rne(a s), a1 = fp16_rne(a s - a0) (exact difference): two 11-bit significands and the sign of
-//     a1 hold 23-24 bits, |r| <= 2^-24 |a s|;  a.b ~= (a1.b0 + a0.b1 + a0.b0) / (s_a s_b): THREE v_mfma_f32_32x32x16_f16, fp32
-//     accumulation; dropped: a1.b1 + r_a.b + a.r_b <= 3 * 2^-24 |a.b|.  s = an exact power of two per operand from a bound on its
-//     magnitude -- the weight's own maximum, and for activations the per-utterance maximum TRACKED BY THE PRODUCING KERNEL
-//     (CTN_AMAX_SLOTS words per utterance, atomic max of bit patterns: exact and order-free).  The low piece is stored times 2^11
-//     and its two cross products have an accumulator of their own, so it is a normal fp16 number for every element down to 2^-27
-//     of the bound.  Measured against fp64 (benchmarks/h3_check.py): max error 1.5e-7 of sum |a||b| (rms 1.3e-8) on every form and
-//     on operands 1e-20 .. 1e6 / utterances 2^80 apart / heavy tails, against 3.9e-7 (2.3e-8) for b6 and 3.8e-7 (2.8e-8) for the
-//     fp32 MFMA: the f16 MFMA rounds once per 16-deep step.
+//     a1 hold 22-23 bits: |a1| <= 2^-11 |a s|, |r| <= 2^-23 |a s| (half an ulp of a1; rms over random data 0.6 * 2^-24);
+//     a.b ~= (a1.b0 + a0.b1 + a0.b0) / (s_a s_b): THREE v_mfma_f32_32x32x16_f16, fp32 accumulation; dropped per product:
+//     a1.b1 + r_a.b + a.r_b, worst case (4 + 2 + 2) 2^-24 = 8 * 2^-24 |a.b| (4.8e-7: larger than one fp32 rounding), 1.2 * 2^-24 rms.
+//     PER PRODUCT h3 is therefore no better than fp32; what makes its GEMM error smaller than the fp32 MFMA's is the
+//     ACCUMULATION: the f16 MFMA adds a 16-deep step exactly and rounds the accumulator once per step, where the fp32 MFMA
+//     (and b6, whose six products go through the same accumulator) round it after every 2-deep (16-deep x 6) step -- rms error
+//     1.3 : 2.3 : 2.8e-8 of sum |a||b| ~ sqrt(number of accumulator roundings).  The dropped products are signed and cancel over
+//     a contraction; when they do not (every operand just below a rounding midpoint, all products positive) the result is off
+//     by 2^-22 = 2.4e-7 .. 4.8e-7 of sum |a||b| -- still under the 6e-7 gate of the tests
+//     (tests/test_gpu_h3.py::test_h3_adversarial_coherent_low_pieces).
+//     s = an exact power of two per operand from a bound on its magnitude -- the weight's own maximum, and for activations the
+//     per-utterance maximum TRACKED BY THE PRODUCING KERNEL (CTN_AMAX_SLOTS words per utterance, atomic max of bit patterns: exact
+//     and order-free).  The low piece is stored times 2^11 and its two cross products have an accumulator of their own, so it is a
+//     normal fp16 number for every element down to 2^-27 of the bound (the bounds above hold for those elements; smaller ones lose
+//     RELATIVE precision gracefully: absolute error <= 2^-50 of the bound).  Measured against fp64 (benchmarks/h3_check.py): max
+//     error 1.5e-7 of sum |a||b| (rms 1.3e-8) on every form and on operands 1e-20 .. 1e6 / utterances 2^80 apart / heavy tails,
+//     against 3.9e-7 (2.3e-8) for b6 and 3.8e-7 (2.8e-8) for the fp32 MFMA.
 //   "b6" (NP = 3 bf16 pieces; every GEMM outside the composite stacks, and the stacks under CTN_GEMM_ARITH=b6):
 //     a = a0 + a1 + a2 EXACTLY,  a0 = bf16_rne(a), a1 = bf16_rne(a - a0), a2 = a - a0 - a1   (both differences are exact in fp32;
 //     |a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|, and a2 has at most 8 significant bits, so its conversion is exact as well)
@@ -76,9 +85,10 @@ template <int AR, bool PRESCALED = false>
 __device__ __forceinline__ void split_x4(const float4& v, bf16x4 (&q)[Ar<AR>::NP], float s) {
     static_assert(AR >= 3 && AR <= 5, "b6 or h3");
     if constexpr (Ar<AR>::F16) {
-        // a s = a0 + a1 + r:  a0 = f16_rne(a s), a1 = f16_rne(a s - a0) (the difference is exact in fp32), |r| <= 2^-24 |a s| as
-        // long as a1 is a normal fp16 number, |r| <= 2^-25 (half an fp16 subnormal step) below that.  W2: the stored low piece
-        // is 2^11 a1 (|a s - a0| <= 2^-11 |a s|, so it stays below the scaled bound): normal for |a s| >= 2^-13
+        // a s = a0 + a1 + r:  a0 = f16_rne(a s), a1 = f16_rne(a s - a0) (the difference is exact in fp32), |r| <= 2^-23 |a s| as
+        // long as a1 is a normal fp16 number (half an ulp of a1, |a1| <= 2^-11 |a s|), |r| <= 2^-25 in absolute terms (half an
+        // fp16 subnormal step) below that.  W2: the stored low piece is 2^11 a1 (|a s - a0| <= 2^-11 |a s|, so it stays below the
+        // scaled bound): normal for |a s| >= 2^-13
         const float x0 = PRESCALED ? v.x : v.x * s, x1 = PRESCALED ? v.y : v.y * s, x2 = PRESCALED ? v.z : v.z * s, x3 = PRESCALED ? v.w : v.w * s;
         const unsigned h0 = pk_f16(x0, x1), h1 = pk_f16(x2, x3);
         const f32x2v w0 = __builtin_convertvector(__builtin_bit_cast(f16x2v, h0), f32x2v);
@@ -519,7 +529,7 @@ __device__ __forceinline__ bf16x8 buf_ld_frag(__amdgpu_buffer_rsrc_t r, int voff
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff + imm, 0, 0));
 }
 
-#ifdef CTN_EXP_B3_TIMELINE       // experiment builds only: per-workgroup phase stamps (benchmarks/b3_timeline.py)
+#ifdef CTN_EXP_B3_TIMELINE       // experiment builds only: per-workgroup phase stamps (benchmarks/gemm_timeline.py)
 __device__ unsigned long long ctn_dbg_tl[8192 * 12];
 #define CTN_TL_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) { ctn_dbg_tl[blockIdx.x * 12 + 2 * (i)] = __builtin_amdgcn_s_memtime(); \
                                   ctn_dbg_tl[blockIdx.x * 12 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)

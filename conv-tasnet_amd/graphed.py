@@ -39,6 +39,14 @@ class GraphedBackprop:
         self.max_snr = None
         was_training = model.training
         model.train()
+        # Overlapped gradient buckets (parallel.enable_overlap) issue collectives from inside the backward pass: not in the
+        # warm-up (their works / covered ranges would be left over for the first real step) and not in the capture (a collective
+        # baked into the graph would replay every step beside finish()'s own reduction of the slice).  The graphed step reduces
+        # the whole flat gradient with ONE collective outside the graph (parallel.allreduce_gradients).
+        saved_buckets = ops._GRAD_BUCKETS
+        ops.set_grad_buckets(None)
+        if getattr(optimizer, "_ctn_buckets", None) is not None:
+            optimizer._ctn_buckets = None
         # eager warm-up on a side stream: sizes every cached workspace and lets the allocator settle before capture
         cur = torch.cuda.current_stream(dev)
         s = torch.cuda.Stream(device=dev)
@@ -51,6 +59,7 @@ class GraphedBackprop:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss, self.max_snr = self._body()
+        del saved_buckets           # (stays uninstalled: every later backward of this optimiser would be un-captured bucket work)
         model.train(was_training)
 
     def _body(self):

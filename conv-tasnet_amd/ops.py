@@ -588,6 +588,11 @@ def _bucket_ranges(nb, direct):
     gb = _GRAD_BUCKETS
     if gb is None or not direct or gb.blocks_per_bucket <= 0 or gb.blocks_per_bucket >= nb:
         return [(0, nb)], None
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture (graphed.GraphedBackprop) a collective would either break the capture or be baked into
+        # the graph and replayed every step beside finish()'s reduction of the same slice: one range, no bucket; the whole
+        # flat gradient is reduced by allreduce_gradients() outside the graph
+        return [(0, nb)], None
     per = gb.blocks_per_bucket
     return [(max(hi - per, 0), hi) for hi in range(nb, 0, -per)], gb
 

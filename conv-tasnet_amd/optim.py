@@ -69,6 +69,9 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         """One memset; the .grad views stay attached (set_to_none is ignored on purpose)."""
+        gb = getattr(self, "_ctn_buckets", None)
+        if gb is not None and (gb.works or gb.covered):
+            gb.reset()              # buckets of a backward pass that never reached allreduce_gradients(): parallel.GradientBuckets.reset
         self.flat_grads.zero_()
         self._written.clear()
         if not self._grad_views_intact():

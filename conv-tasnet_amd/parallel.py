@@ -68,6 +68,16 @@ class GradientBuckets:
         self.blocks_per_bucket = int(blocks_per_bucket)
         self.works, self.covered = [], []
 
+    def reset(self):
+        """Forget the buckets of a backward pass that was not followed by allreduce_gradients() (an exception, a skipped step,
+        a diagnostic backward): wait for what was started -- every rank started the same collectives, or the job is lost
+        anyway -- and drop the covered ranges, so that the next finish() reduces every slice of the NEW gradients.
+        Called by FlatAdam.zero_grad().  A backward pass under enable_overlap must be followed by allreduce_gradients() on
+        every rank (or by zero_grad() on every rank)."""
+        for w in self.works:
+            w.wait()
+        self.works, self.covered = [], []
+
     def bucket_ready(self, sinks):
         flat = self.opt.flat_grads
         base, esz = flat.data_ptr(), flat.element_size()

@@ -116,9 +116,13 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
 
 /* ---- "h3" arithmetic: fp32-faithful products from TWO fp16 pieces per operand (three f16 MFMAs instead of b6's six) ------
  * replaces the same fp32 nn.Conv1d(*, *, 1) layers (src/conv_tasnet.py:223,262) inside the composite stacks.
- *   a s = a0 + a1 + r,  a0 = fp16_rne(a s), a1 = fp16_rne(a s - a0):  two 11-bit significands + the sign of a1 hold 23-24 bits,
- *   |r| <= 2^-24 |a s|;   a.b ~= (a1.b0 + a0.b1 + a0.b0) / (s_a s_b)  on v_mfma_f32_32x32x16_f16, fp32 accumulation; dropped:
- *   a1.b1 + r_a.b + a.r_b, <= 3 * 2^-24 |a.b| -- the size of the rounding an fp32 FMA chain commits per step (b6 drops 2 * 2^-24).
+ *   a s = a0 + a1 + r,  a0 = fp16_rne(a s), a1 = fp16_rne(a s - a0):  two 11-bit significands + the sign of a1 hold 22-23 bits,
+ *   |a1| <= 2^-11 |a s|, |r| <= 2^-23 |a s|;   a.b ~= (a1.b0 + a0.b1 + a0.b0) / (s_a s_b)  on v_mfma_f32_32x32x16_f16, fp32
+ *   accumulation; dropped per product: a1.b1 + r_a.b + a.r_b, <= 8 * 2^-24 |a.b| in the worst case (4.8e-7), 1.2 * 2^-24 rms (b6
+ *   drops 2 * 2^-24).  A single product is thus NOT better than an fp32 one; the GEMM is, because the f16 MFMA rounds its fp32
+ *   accumulator once per 16-deep step where the fp32 MFMA rounds it every 2-deep step (measured rms error of every form 1.3e-8
+ *   of sum |a||b| against 2.8e-8, max 1.5e-7 against 3.8e-7).  Coherent worst case (all operands positive, each just below a
+ *   rounding midpoint): 2.4e-7 .. 4.8e-7 of sum |a||b|, tested (tests/test_gpu_h3.py).
  * fp16 has 5 exponent bits, so every operand is brought into range by an exact power-of-two scale s derived from a bound on
  * its magnitude: the weight's own maximum (computed by ctn_split_h3_batch), and for activations the per-utterance maximum
  * max |X[m]| TRACKED BY THE KERNEL THAT PRODUCED X -- `amax` arrays: [M][CTN_AMAX_SLOTS] unsigned, bit patterns of non-negative
@@ -127,8 +131,10 @@ int ctn_pw_dgrad_gln_planes(const void* Wp, const float* dOut, float* dN, int M,
  * over the slots; the caller zeroes the array before the producer runs.  Producers: ctn_absmax_rows (any tensor), ctn_pw_gemm_h3 (residual epilogue, out_amax), ctn_dw_fwd and
  * ctn_gln_prelu_bwd (amax_out).  With an operand prologue the scale comes from the bound
  * max|gamma| * rstd * (max(1,|alpha|) * amax + |mean|) + max|beta|  (pro_gbmax = {max|gamma|, max|beta|}: ctn_absmax_batch).
- * Scaled values stay below 2^14 (fp16 holds 65504).  Elements within 2^-17 of their utterance's maximum keep the full
- * 2^-24 relative precision; smaller ones degrade gracefully (absolute error <= 2^-39 of the maximum).  Same tiles, statistics
+ * Scaled values stay below 2^15 (fp16 holds 65504).  The bounds above hold for every element down to 2^-27 of its operand's bound
+ * (the low piece is stored times 2^11 and accumulated separately, so it stays a normal fp16 number); smaller elements lose RELATIVE
+ * precision gracefully (absolute error <= 2^-50 of the bound).  The scale is per UTTERANCE (per weight matrix): an element far below
+ * its utterance's maximum is covered by that window, not by a scale of its own.  Same tiles, statistics
  * layouts (ctn_pw_stats_parts of the split arithmetics), epilogues and fixed-order reductions as the plain entry points.
  * These entry points do not depend on ctn_tune("arith"); R >= 64 (weight gradient: both sides >= 32). */
 size_t ctn_split_h3_bytes(int R, int Cn);

@@ -164,15 +164,17 @@ def ola_cases():
         save("ola_f_%d_%d_%d" % (K, L, s), signal=sig, step=s, result=overlap_and_add(sig, s))
 
 
-def solver_case():
-    """Reference Solver on CPU: DataParallel is a pass-through with 0 GPUs and supplies .module."""
-    hp = dict(N=16, L=20, B=8, H=16, P=3, X=2, R=1, C=2)
+def solver_case(name="solver_traj", hp=None, T=2005, epochs=4):
+    """Reference Solver on CPU: DataParallel is a pass-through with 0 GPUs and supplies .module.
+    solver_traj: the round-1 fixture (tiny widths: the product runs its fp32 kernels on every layer but one);
+    solver_traj_wide: B = 64, H = 128 -- every 1x1 convolution of the stack has >= 64 rows, so the product's default h3
+    arithmetic (and b6) is what the reference's recorded trajectory is compared with."""
+    hp = dict(N=16, L=20, B=8, H=16, P=3, X=2, R=1, C=2) if hp is None else hp
     torch.manual_seed(3)
     model = ConvTasNet(hp["N"], hp["L"], hp["B"], hp["H"], hp["P"], hp["X"], hp["R"], hp["C"])
     init_sd = {k: v.clone() for k, v in model.state_dict().items()}
     wrapped = torch.nn.DataParallel(model)
     opt = torch.optim.Adam(wrapped.parameters(), lr=1e-3, weight_decay=0)
-    T = 2005
     batches = []
     for i in range(3):
         mix, lens, src = synth_batch(900 + 2 * i, 2, T)
@@ -188,7 +190,6 @@ def solver_case():
     ref_solver_mod.cal_loss = spy
     import tempfile
     tmp = tempfile.mkdtemp()
-    epochs = 4
     arg = (0, epochs, 1, 0, 5, tmp, 0, "", "final.pth.tar", 1000, 0, 0, "x")
     s = Solver({"tr_loader": batches, "cv_loader": cv}, wrapped, opt, arg)
     s.train()
@@ -203,7 +204,7 @@ def solver_case():
     pkg = torch.load(os.path.join(tmp, "final.pth.tar"), weights_only=False)
     arrs["pkg_keys"] = np.array(sorted(pkg.keys()))
     arrs["pkg_epoch"] = pkg["epoch"]
-    save("solver_traj", **arrs)
+    save(name, **arrs)
 
 
 def init_case():
@@ -271,6 +272,9 @@ if __name__ == "__main__":
         data_case()
         sys.exit(0)
     tiny = dict(N=64, L=20, B=32, H=64, P=3, X=2, R=2, C=2)
+    if "--solver-wide-only" in sys.argv:
+        solver_case("solver_traj_wide", dict(N=64, L=20, B=64, H=128, P=3, X=2, R=2, C=2), T=4005, epochs=4)
+        sys.exit(0)
     if "--bn-only" in sys.argv:
         bn_case("model_tiny_bn", T=4005, M=3, seed=5, **tiny)
         bn_case("model_tiny_bn_causal", T=3001, M=2, seed=6, causal=True, **tiny)
@@ -288,4 +292,5 @@ if __name__ == "__main__":
     ola_cases()
     init_case()
     solver_case()
+    solver_case("solver_traj_wide", dict(N=64, L=20, B=64, H=128, P=3, X=2, R=2, C=2), T=4005, epochs=4)
     data_case()

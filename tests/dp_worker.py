@@ -62,6 +62,35 @@ model, opt, sa = phase_a(True)
 res = {"losses": list(sa.iter_losses[:3]), "cv_a": float(sa.cv_loss[0]), "params": opt.flat_params.detach().cpu().clone(),
        "buckets_equal_single_collective": bool(torch.equal(opt.flat_params, plain))}
 
+
+
+def phase_paper(overlap):
+    """Two steps at the PAPER's widths and depth (B = 256, H = 512, 32 blocks: the default h3 arithmetic, four buckets of eight
+    blocks = 8.4 MB each + the front / back-end remainder), one 1-s utterance per rank: buckets against the single collective."""
+    os.environ["CTN_DP_OVERLAP"] = "1" if overlap else "0"
+    torch.manual_seed(7)
+    m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(dev)
+    o = FlatAdam(m.parameters(), lr=1e-3)
+    parallel.broadcast_parameters(o.flat_params)
+    gb = parallel.enable_overlap(o, 8)
+    assert (gb is not None) == (overlap and world > 1)
+    g = SyntheticLoader(1, 1, samples=8000)
+    for step in range(2):
+        src = torch.stack([g._utt(900 + 2 * step + rank)]).to(dev)
+        o.zero_grad()
+        ctn.cal_loss(src, m(src.sum(1)), torch.full((1,), 8000, dtype=torch.long, device=dev))[0].backward()
+        o.step(max_grad_norm=5.0, grad_scale=parallel.allreduce_gradients(o))
+    ctn.ops.set_grad_buckets(None)
+    return o.flat_params.detach().clone()
+
+
+pp_plain = phase_paper(False)
+pp_buckets = phase_paper(True)
+res["paper_buckets_equal_single_collective"] = bool(torch.equal(pp_plain, pp_buckets))
+res["paper_params_finite"] = bool(torch.isfinite(pp_buckets).all())
+res["gemm_arith"] = ctn.gemm_arith()
+del pp_plain, pp_buckets
+
 opt.param_groups[0]["lr"] = 1e-12
 arg = (1, 12, 1, 1, 5, save, 0, "", "b.pth.tar", 1000, 0, 0, "x")
 sb = Solver({"tr_loader": train, "cv_loader": cv}, model, opt, arg)

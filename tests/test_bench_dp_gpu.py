@@ -20,7 +20,10 @@ def test_bench_two_ranks_prints_one_complete_line(bench_children):
     assert len(lines0) == 1 and lines1 == [], "rank 0 prints ONE JSON line, the other ranks none"
     j = json.loads(lines0[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
-    assert j["unit"] == "utterances/sec" and j["value"] > 0 and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert j["unit"] == "utterances/sec" and j["value"] > 0 and j["dtype"].startswith("f32 (") and j["vs_baseline"] is None
+    d = j["distributed"]                                   # what the collective library saw (RCCL on the driver's node; gloo here)
+    assert d["rccl_ranks"] == 2 and len(d["ranks"]) == 2 and d["backend"] == "gloo" and d["gradient_allreduce_bytes_per_step"] > 0
+    assert j["roofline"]["gradient_allreduce"]["exposed_us_per_step"] >= 0
     assert j["config"]["global_batch"] == 4 and j["config"]["parallelism"] == "dp2"
     assert abs(j["value"] - 4 * 3 / (j["ms_per_step"] * 3e-3)) < 0.01 * j["value"]      # whole-job utterances over the timed region
     assert j["mean_loss"] == j["mean_loss"] and abs(j["mean_loss"]) < 1e3                # finite

@@ -21,6 +21,9 @@ def test_two_rank_product_training_matches_single_process(dp_children):
     # the bucketed all-reduce issued during the backward pass (one bucket per repeat behind the weight-gradient stream + the
     # remainder) gives bitwise the parameters of the single collective after it (two ranks: a + b == b + a)
     assert r0["buckets_equal_single_collective"] and r1["buckets_equal_single_collective"] and one["buckets_equal_single_collective"]
+    # the same at the paper's widths and depth under the default arithmetic (four 8.4 MB buckets + remainder, h3 GEMMs)
+    for r in (r0, r1, one):
+        assert r["paper_buckets_equal_single_collective"] and r["paper_params_finite"], r["gemm_arith"]
     # ragged shards (5 + 3 utterances): the weighted global-minibatch loss equals the single-process loss on all 8
     for a, b, c in zip(r0["losses"], r1["losses"], one["losses"]):
         assert a == b, "ranks report different global losses"

@@ -11,9 +11,11 @@ What is asserted, with the limits of the fp32 arithmetic (nothing is widened for
     per-kernel path that measures them and the composite that tracks them agree bit for bit (tests/test_gpu_train.py);
   * edge cases: an all-zero utterance, NaN / inf confined to their utterance, elements far below their utterance's maximum
     (absolute error <= 2^-38 of the maximum: graceful, documented loss of RELATIVE precision);
-  * at the paper config: the gradients of one training step against the fp64 CPU oracle -- h3's error is not above the fp32
-    MFMA's (observed 2.7e-6 against 1.5e-5 and 1.8e-5 for b6, benchmarks/arith_grad_err.py) -- and a 10-step trajectory against
-    the same 10 steps of the oracle in fp64: h3 follows it at least as closely as the fp32 MFMA does.
+  * at the paper config: the gradients of one training step against the fp64 CPU oracle at M = 1 (computed in the test) and at
+    the bench's batch M = 8 (fixture) -- h3's error is not above the fp32 MFMA's (observed 2.7e-6 / 3.1e-6 against 1.5e-5 /
+    1.7e-5 and 1.8e-5 / 2.0e-5 for b6) -- and a 10-step trajectory against the same 10 steps of the oracle in fp32 (the
+    reference's arithmetic) and in fp64, plus every step from a common state (what separates free-running trajectories is
+    Adam's eps on zero-gradient elements, not accuracy: see test_trajectories_of_the_three_arithmetics).
 """
 import numpy as np
 import pytest
@@ -146,6 +148,49 @@ def test_h3_gemm_forms_against_fp64(scenario, M, B, H, K):
     scw2 = torch.einsum("mrk,mck->rc", d(gB).abs(), nrm.abs())
     check(ops.pw_wgrad_h3(gB, xH, B, H, K, agB, axH, pro=(gam, bet, a, ms), gbmax=gbm),
           lambda: ops.pw_wgrad(gB, xH, B, H, K, pro=(gam, bet, a, ms)), refw2, scw2)
+
+
+def test_h3_adversarial_coherent_low_pieces():
+    """The worst case of the h3 product, built on purpose: every operand is POSITIVE and sits just below the midpoint between two
+    fp16 grid points of its scaled binade, x = c (1 + j 2^-10 + 2^-11 - 2^-17), so that its low piece is +(2^-11 - 2^-17) c for every
+    element -- the dropped products a1.b1 are then all positive and add up coherently: the result is LOW by
+    2^-22 / ((1 + j_a 2^-10)(1 + j_b 2^-10)) of every product, 1.1e-7 of sum |a||b| on average over j (up to 2.4e-7 for operands at
+    the bottom of their binade), where random data cancels the dropped terms.  The second pattern also puts the remainder r at its
+    largest magnitude 2^-23 |x| (a tie of the second rounding, resolved the same way for every element).
+    Asserted: the coherent term is there and has the predicted sign and size (mean signed error), and the maximum error -- the
+    coherent term plus the accumulator roundings, which on all-positive data are relative to the whole running sum -- stays under
+    the 6e-7 gate of every other GEMM test or within 1.25x of the fp32 MFMA's on the same data.
+    Per product the bound is  |a.b - h3(a, b)| <= (4 + 2 + 2) 2^-24 |a.b| = 4.8e-7 |a.b|  (a1.b1 <= 2^-22, r_a.b and a.r_b <= 2^-23
+    each; rms 1.2 2^-24 on random data): csrc/ctn_gemm_b3.h."""
+    M, B, H, K = 2, 256, 512, 515
+    Kp = ops.padded_frames(K)
+    for tail, coherent in ((2.0 ** -11 - 2.0 ** -17, True), (2.0 ** -11 - 2.0 ** -22 - 2.0 ** -23, False)):
+        jx = torch.randint(0, 1024, (M, B, K), generator=g(1)).double()
+        jw = torch.randint(0, 1024, (H, B), generator=g(2)).double()
+        x64 = 8.0 * (1.0 + jx * 2.0 ** -10 + tail)
+        w64 = 2.0 ** -6 * (1.0 + jw * 2.0 ** -10 + tail)
+        x, w = pad(x64.float(), Kp).to(DEV), w64.float().to(DEV)
+        assert torch.equal(x[..., :K].double().cpu(), x64) and torch.equal(w.double().cpu(), w64)       # exactly representable in fp32
+        ref = torch.einsum("rc,mck->mrk", w64, x64)                                  # all terms positive: sum |a||b| = the result
+        out, _ = ops.pw_gemm_h3(ops.h3_pieces(w, H, B, False), x, H, B, K, ops.absmax_rows(x))
+        rel = (out[..., :K].double().cpu() - ref) / ref
+        err, signed = float(rel.abs().max()), float(rel.mean())
+        with ctn.gemm_arithmetic("fp32"):
+            e32 = float(((ops.pw_gemm(w, x, H, B, K)[0][..., :K].double().cpu() - ref) / ref).abs().max())
+        print("h3 adversarial pattern (low piece = %.6e of the element): max error %.3e (fp32 MFMA %.3e), mean signed error %+.3e of sum |a||b|"
+              % (tail, err, e32, signed))
+        if coherent:
+            assert -1.7e-7 < signed < -0.6e-7, signed           # predicted -2^-22 E[1 / (1 + u)]^2 = -1.1e-7
+        assert abs(signed) < 4.8e-7
+        assert err < 6e-7 or err <= 1.25 * e32, (tail, err, e32)
+        # the weight gradient sees the same operands on both sides (frames as the contraction)
+        gH = pad((2.0 ** -6 * (1.0 + torch.randint(0, 1024, (M, H, K), generator=g(3)).double() * 2.0 ** -10 + tail)).float(), Kp).to(DEV)
+        refw = torch.einsum("mrk,mck->rc", gH[..., :K].double().cpu(), x64)
+        dw = ops.pw_wgrad_h3(gH, x, H, B, K, ops.absmax_rows(gH), ops.absmax_rows(x))
+        errw = float(((dw.double().cpu() - refw).abs() / refw).max())
+        with ctn.gemm_arithmetic("fp32"):
+            ew32 = float(((ops.pw_wgrad(gH, x, H, B, K).double().cpu() - refw).abs() / refw).max())
+        assert errw < 6e-7 or errw <= 1.25 * ew32, (tail, errw, ew32)
 
 
 @pytest.mark.parametrize("blocks", [512, 100])
@@ -305,37 +350,106 @@ def test_h3_paper_config_gradients_against_the_fp64_oracle():
     assert err["h3"][0] <= 1.1 * err["fp32"][0], err
 
 
-def test_trajectories_against_the_fp64_oracle():
-    """10 optimiser steps (fwd + PIT loss + bwd + clip(5) + Adam, lr 1e-3) of the paper config on the bench's batch under the fp32
-    MFMA, b6 and h3, from the same weights on the same data, against the SAME 10 steps of the CPU oracle run in fp64
-    (tests/golden/paper_traj_fp64.npz, oracle/make_traj_golden.py).  Observed on the MI355X: every fp32-accumulating arithmetic
-    (fp32 MFMA, b6 -- and the CPU in fp32, benchmarks/trajectory_vs_oracle.py) drifts from the fp64 run by the same ~4e-3 dB /
-    1.4 % of the distance travelled, together (they round alike); h3, whose f16 MFMAs accumulate 16-deep steps before rounding,
-    stays within 1e-4 dB.  Asserted: h3 follows the fp64 trajectory at least as closely as the fp32 MFMA does."""
+def test_paper_config_gradients_at_the_bench_batch():
+    """One training step of BASELINE configs[1] on the bench's batch (M = 8 x 4 s) under h3, b6 and the fp32 MFMA against the fp64
+    oracle gradient of tests/golden/paper_grad_fp64_m8.npz (oracle/make_grad_golden.py, generated in the build container): the loss,
+    every 997th gradient element and the norm of every tensor.  Observed on the MI355X over ALL elements
+    (benchmarks/arith_grad_families.py, profiles/r04_b_grad_families.txt): |g - g64| / |g64| = 3.1e-6 (h3), 2.0e-5 (b6), 1.7e-5
+    (fp32 MFMA) -- and 2.7e-6 / 1.8e-5 / 1.5e-5 at M = 1 and 2: the error does not grow with the batch under any arithmetic."""
+    gd = load_golden("paper_grad_fp64_m8")
+    stride = int(gd["stride"])
+    cfg, m, mix, lens, src = _paper_step_setup(int(gd["M"]))
+    g64 = gd["g"].astype(np.float64)
+    err = {}
+    for arith, bound in (("h3", 1e-5), ("b6", 6e-5), ("fp32", 5e-5)):
+        with ctn.gemm_arithmetic(arith):
+            m.zero_grad()
+            loss = ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0]
+            loss.backward()
+            ops.join_side_stream()
+            g = torch.cat([p.grad.detach().reshape(-1) for _, p in m.named_parameters()])
+            e = float(np.linalg.norm(g[::stride].double().cpu().numpy() - g64) / np.linalg.norm(g64))
+            norms = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+            en = float(np.max(np.abs(norms - gd["norms"]) / (gd["norms"] + 1e-6 * gd["norms"].max())))
+            err[arith] = (e, abs(float(loss.detach()) - float(gd["loss"])), en)
+            assert err[arith][1] < 1e-3 and e < bound and en < 2e-3, (arith, err[arith])
+    print("paper config, M = 8: (|g - g_fp64| / |g_fp64| on every %dth element, loss error [dB], worst tensor-norm error) %s" % (stride, err))
+    assert err["h3"][0] <= 1.1 * err["fp32"][0], err
+
+
+def test_trajectories_of_the_three_arithmetics():
+    """10 optimiser steps (fwd + PIT loss + bwd + clip(5) + Adam, lr 1e-3, eps 1e-8: src/solver.py:181-198) of the paper config on the
+    bench's batch under the fp32 MFMA, b6 and h3, from the same weights on the same data, against
+      (a) the CPU oracle in FP32 -- the reference's own arithmetic (tests/golden/paper_traj_cpu_fp32.npz, oracle/make_traj_fp32_golden.py),
+      (b) the CPU oracle in fp64 (tests/golden/paper_traj_fp64.npz),
+      (c) each other step by step FROM THE SAME STATE (the fp32-MFMA run's parameters and Adam moments before every step).
+    What separates such runs (benchmarks/traj_adam_diag.py, traj_elem_diag.py): not the size of the gradient
+    error (1e-5 .. 3e-4 relative at every step under every arithmetic) but Adam with eps = 1e-8 on elements whose gradient is
+    (almost) zero.  A mask channel whose ReLU is off for every frame has an exactly zero gradient and zero Adam moments; the first
+    step at which one frame switches it on gives its 256 weights a gradient of ~1e-5 of the typical size, and Adam turns that into a
+    FULL-SIZE step lr * sign(g) -- 5.2e-4 per weight.  On this batch that happens at step 5 (row 187 of the mask convolution): its
+    sign is decided by which frames are barely on, i.e. by differences of ~1e-7 in the stack's output; b6, the fp32 MFMA and the CPU
+    in fp32 see -1.4e-5 there, h3 (and, by its losses, the fp64 run) +5.1e-5, the channel comes fully alive in one family of runs
+    and dies again in the other, and the loss of step 6 differs by 3.9e-3 dB.  The same run-to-run sensitivity exists BETWEEN fp32
+    implementations on other data; it is a property of the reference's optimiser rule, not an accuracy ranking.  Hence:
+      (a) every arithmetic follows the reference arithmetic's trajectory within 4e-4 dB up to step 5 (observed <= 2e-4); from step 6
+          on the runs on the fixture's side of the event stay within 2e-4 dB and the others within 8e-3 dB (observed 3.9e-3).  Two
+          runs of the REFERENCE'S OWN fp32 arithmetic land on different sides: the CPU oracle with 8 threads (this fixture) gives
+          -0.310169 at step 6, with 16 threads on the GPU box's host -0.306235;
+      (b) h3 follows the fp64 trajectory within 1e-3 dB over all 10 steps (observed 1e-5), b6 / fp32 within 8e-3 dB;
+      (c) from the same state, every step's loss agrees within 1e-4 dB and the parameter update within 5 % (observed <= 1.5 %, at the
+          event; 0.1 % otherwise) -- the bound that catches a drift of an arithmetic against the reference's without depending on
+          which side of an event a free-running trajectory falls."""
     from conv_tasnet_amd.optim import FlatAdam
     from conv_tasnet_amd.train import SyntheticLoader
-    gd = load_golden("paper_traj_fp64")
-    steps, stride = int(gd["steps"]), int(gd["stride"])
-    mix, lens, src = next(iter(SyntheticLoader(1, int(gd["M"]), samples=32000)))
+    g64, g32 = load_golden("paper_traj_fp64"), load_golden("paper_traj_cpu_fp32")
+    steps, stride = int(g64["steps"]), int(g64["stride"])
+    assert int(g32["steps"]) == steps and int(g32["M"]) == int(g64["M"])
+    mix, lens, src = next(iter(SyntheticLoader(1, int(g64["M"]), samples=32000)))
     mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
-    dev = {}
+
+    def one_step(m, opt):
+        opt.zero_grad()
+        loss = ctn.cal_loss(src, m(mix), lens)[0]
+        loss.backward()
+        opt.step(max_grad_norm=5.0)
+        return float(loss.detach())
+
+    dev, snaps = {}, []
     for arith in ("fp32", "b6", "h3"):
         ctn.set_gemm_arith(arith)
         torch.manual_seed(0)
         m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(DEV)
         opt = FlatAdam(m.parameters(), lr=1e-3)
         losses = []
-        for _ in range(steps):
-            opt.zero_grad()
-            loss = ctn.cal_loss(src, m(mix), lens)[0]
-            loss.backward()
-            opt.step(max_grad_norm=5.0)
-            losses.append(float(loss.detach()))
+        for s in range(steps):
+            if arith == "fp32":
+                snaps.append([opt.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), s, None, None])
+            losses.append(one_step(m, opt))
+            if arith == "fp32":
+                snaps[s][4], snaps[s][5] = losses[-1], opt.flat_params - snaps[s][0]
         p = torch.cat([q.detach().reshape(-1) for _, q in m.named_parameters()])[::stride].double().cpu().numpy()
-        dev[arith] = (max(abs(a - b) for a, b in zip(losses, gd["losses"])),
-                      float(np.linalg.norm(p - gd["p_final"].astype(np.float64)) / np.linalg.norm(gd["p_final"].astype(np.float64) - gd["p0"].astype(np.float64))))
+        d32 = [abs(a - b) for a, b in zip(losses, g32["losses"])]
+        dev[arith] = dict(fp64=max(abs(a - b) for a, b in zip(losses, g64["losses"])), early=max(d32[:6]), late=max(d32[6:]),
+                          p64=float(np.linalg.norm(p - g64["p_final"].astype(np.float64)) / float(g64["travelled"])) * stride ** 0.5)
+        if arith != "fp32":                 # (c): every step again from the fp32-MFMA run's state
+            worst_l, worst_u = 0.0, 0.0
+            for p0, m1, m2, s, l32, u32 in snaps:
+                opt.flat_params.copy_(p0); opt.exp_avg.copy_(m1); opt.exp_avg_sq.copy_(m2); opt._step = s
+                l = one_step(m, opt)
+                worst_l = max(worst_l, abs(l - l32))
+                worst_u = max(worst_u, float((opt.flat_params - p0 - u32).double().norm() / u32.double().norm()))
+            dev[arith].update(same_state_loss=worst_l, same_state_update=worst_u)
     ctn.set_gemm_arith(DEFAULT_ARITH)
-    print("10 steps against the fp64 oracle: (max |loss difference| [dB], |p - p_fp64| / |p_fp64 - p0| on every %dth parameter) %s" % (stride, dev))
-    assert gd["losses"][-1] < gd["losses"][0] - 1.0
-    assert dev["h3"][0] < 1e-3                                              # the north star's loss budget, over a whole trajectory
-    assert dev["h3"][0] <= dev["fp32"][0] + 1e-5 and dev["h3"][1] <= dev["fp32"][1] + 1e-4, dev
+    print("10 steps of the paper config: %s" % dev)
+    assert g64["losses"][-1] < g64["losses"][0] - 1.0
+    for arith in ("fp32", "b6", "h3"):
+        assert dev[arith]["early"] < 4e-4, (arith, dev[arith])
+    # (which family of runs the committed CPU-fp32 fixture belongs to is itself decided by the event: the build container's 8-thread
+    # run gives -0.310169 at step 6, the GPU box's 16-thread run of the same code -0.306235, profiles/r03_h3_traj_vs_cpu_oracle_m8.txt)
+    for arith in ("fp32", "b6", "h3"):
+        assert dev[arith]["late"] < 8e-3, (arith, dev[arith])
+    assert min(dev[a]["late"] for a in ("fp32", "b6", "h3")) < 2e-4, dev       # at least one arithmetic is on the fixture's side of the event
+    assert dev["h3"]["fp64"] < 1e-3 and dev["b6"]["fp64"] < 8e-3 and dev["fp32"]["fp64"] < 8e-3, dev
+    for arith in ("b6", "h3"):
+        assert dev[arith]["same_state_loss"] < 1e-4 and dev[arith]["same_state_update"] < 5e-2, (arith, dev[arith])

@@ -18,8 +18,8 @@ from conv_tasnet_amd.solver import Solver  # noqa: E402
 DEV = "cuda:0"
 
 
-def _traj_setup():
-    g = load_golden("solver_traj")
+def _traj_setup(name="solver_traj"):
+    g = load_golden(name)
     N, L, B, H, P, X, R, C = [int(v) for v in g["cfg"]]
     m = ctn.ConvTasNet(N, L, B, H, P, X, R, C)
     m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p0:")})
@@ -28,10 +28,13 @@ def _traj_setup():
     return g, m.to(DEV), batches
 
 
+@pytest.mark.parametrize("fixture", ["solver_traj", "solver_traj_wide"])
 @pytest.mark.parametrize("flat", [True, False])
-def test_solver_trajectory_matches_reference_solver(tmp_path, flat):
-    """Same weights, batches, Adam(1e-3), clip 5, 4 epochs as the run recorded from src/solver.py."""
-    g, m, batches = _traj_setup()
+def test_solver_trajectory_matches_reference_solver(tmp_path, flat, fixture):
+    """Same weights, batches, Adam(1e-3), clip 5, 4 epochs as the run recorded from src/solver.py (oracle/make_golden.py).
+    solver_traj: the tiny config (one layer with >= 64 rows); solver_traj_wide: B = 64, H = 128, so that every GEMM of the stacks
+    runs the arithmetic under test (h3 / b6) against the REFERENCE's recorded 12-step trajectory."""
+    g, m, batches = _traj_setup(fixture)
     opt = FlatAdam(m.parameters(), lr=1e-3) if flat else torch.optim.Adam(m.parameters(), lr=1e-3)
     arg = (1, int(g["epochs"]), 1, 0, 5, str(tmp_path), 0, "", "final.pth.tar", 1000, 0, 0, "x")
     s = Solver({"tr_loader": batches, "cv_loader": batches[:1]}, m, opt, arg)
@@ -44,6 +47,48 @@ def test_solver_trajectory_matches_reference_solver(tmp_path, flat):
         np.testing.assert_allclose(v.cpu().numpy(), g["p1:" + k], atol=3e-4, err_msg=k)
     pkg = torch.load(tmp_path / "final.pth.tar", weights_only=False)
     assert sorted(pkg.keys()) == sorted(str(k) for k in g["pkg_keys"]) and pkg["epoch"] == int(g["pkg_epoch"])
+
+
+@pytest.mark.parametrize("side", [True, False])
+@pytest.mark.parametrize("norm,causal", [("gLN", False), ("cLN", True)])
+def test_bucketed_backward_equals_the_single_call(norm, causal, side):
+    """The per-bucket backward of the stacks (parallel.enable_overlap: one composite call per repeat, last repeat first, the
+    weight-gradient stream left un-joined between calls, its own workspace per un-joined call, a fresh operand maximum at every
+    range start) at widths where the arithmetic under test runs (B = 64, H = 128: h3 / b6 pieces; the two-rank test of
+    tests/dp_worker.py uses B = 16, H = 32 = the fp32 kernels): with a stand-in GradientBuckets whose bucket_ready() does
+    nothing, every gradient must be BITWISE the single-call backward's -- with and without the second stream."""
+    from conv_tasnet_amd import ops
+
+    class Stub:
+        blocks_per_bucket = 2
+        works, covered = [], []
+        calls = 0
+
+        def bucket_ready(self, sinks):
+            Stub.calls += 1
+
+    torch.manual_seed(4)
+    m = ctn.ConvTasNet(64, 20, 64, 128, 3, 2, 3, 2, norm_type=norm, causal=causal).to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    mix, lens, src = O.synth_batch(40, 3, 4005)
+    mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
+    saved_side = ops._SIDE_ENABLED
+    ops._SIDE_ENABLED = side
+    try:
+        grads = []
+        for gb in (None, Stub()):
+            ops.set_grad_buckets(gb)
+            opt.zero_grad()
+            ctn.cal_loss(src, m(mix), lens)[0].backward()
+            ops.join_side_stream(opt.flat_grads.device)
+            torch.cuda.synchronize()
+            grads.append(opt.flat_grads.clone())
+        assert Stub.calls == 3                              # X = 2 blocks per bucket, R = 3 repeats
+        assert float(grads[0].abs().max()) > 0
+        assert torch.equal(grads[0], grads[1]), "%d gradient elements differ" % int((grads[0] != grads[1]).sum())
+    finally:
+        ops.set_grad_buckets(None)
+        ops._SIDE_ENABLED = saved_side
 
 
 def test_flatadam_state_interchanges_with_torch_adam():
@@ -164,6 +209,25 @@ def test_streaming_causal_inference_equals_full_forward():
     assert float((got - full).abs().max()) <= 2e-6 * float(full.abs().max())
     with pytest.raises(ValueError):
         StreamingSeparator(ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2).to(DEV))
+    # ... and against the REFERENCE's own output: the causal cLN fixture recorded from src/conv_tasnet.py (oracle/make_golden.py).
+    # Its 3001 samples give 299 frames over samples 0 .. 2999 (the 3001st output sample is the reference's zero padding), exactly
+    # the frames of a 3000-sample stream.
+    gd = load_golden("model_tiny_cln_causal")
+    N, L, B, H, P, X, R, C = [int(v) for v in gd["cfg"]]
+    mg = ctn.ConvTasNet(N, L, B, H, P, X, R, C, norm_type="cLN", causal=True, mask_nonlinear=str(gd["mask_nonlinear"]))
+    mg.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in gd.items() if k.startswith("p:")})
+    mg = mg.to(DEV).eval()
+    mixg, refg = torch.from_numpy(gd["mixture"])[:, :3000], torch.from_numpy(gd["est_source_raw"])[..., :3000]
+    sg = StreamingSeparator(mg, batch=2)
+    outs, pos = [], 0
+    for n in (17, 100, 3, 180):
+        outs.append(sg.push(mixg[:, pos:pos + n * (L // 2)]))
+        pos += n * (L // 2)
+    assert pos == 3000
+    outs.append(sg.flush())
+    gotg = torch.cat(outs, dim=2).cpu()
+    assert gotg.shape == refg.shape
+    assert float((gotg - refg).abs().max()) <= 2e-5 * float(refg.abs().max())
 
 
 def test_input_dtype_and_layout_are_normalised():
@@ -193,11 +257,24 @@ def test_graphed_backprop_replays_the_eager_step():
     cfg = dict(N=64, L=20, B=32, H=64, P=3, X=3, R=2, C=2)
     batches = list(SyntheticLoader(3, 2, samples=8000))
 
+    class Buckets:                  # what parallel.enable_overlap installs for N > 1: must not reach the capture
+        blocks_per_bucket = 3
+        works, covered = [], []
+
+        def bucket_ready(self, sinks):
+            raise AssertionError("a gradient bucket was issued inside the warm-up or the capture of GraphedBackprop")
+
     def run(graph):
         torch.manual_seed(3)
         model = ctn.ConvTasNet(**cfg).to(DEV)
         opt = FlatAdam(model.parameters(), lr=1e-3)
+        if graph:
+            from conv_tasnet_amd import ops
+            opt._ctn_buckets = Buckets()
+            ops.set_grad_buckets(opt._ctn_buckets)
         stepper = GraphedBackprop(model, opt, batches[0]) if graph else None
+        if graph:
+            assert ops._GRAD_BUCKETS is None and opt._ctn_buckets is None      # one collective outside the graph instead
         losses, grads = [], []
         for mix, lens, src in batches:
             mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
