@@ -45,16 +45,33 @@ def apply(cfg):
             ops._FWD_DUAL = bool(int(v))
         elif k == "cln_side":
             ops._CLN_SIDE = bool(int(v))
+        elif k == "hp":                     # 1: run the step's main chain on a HIGH-priority stream (the weight-gradient stream stays normal)
+            global HP
+            HP = bool(int(v))
         else:
             ctn.lib.call("ctn_tune", k.encode(), int(v))
     ops._ws_cache.clear()
 
 
-def step():
+HP = False
+_hp_stream = torch.cuda.Stream(device=dev, priority=-1)
+
+
+def _step():
     opt.zero_grad()
     loss = ctn.cal_loss(src, m(mix), lens)[0]
     loss.backward()
     opt.step(max_grad_norm=5.0)
+
+
+def step():
+    if HP:
+        _hp_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(_hp_stream):
+            _step()
+        torch.cuda.current_stream().wait_stream(_hp_stream)
+    else:
+        _step()
 
 
 res = {c: [] for c in configs}

@@ -372,7 +372,7 @@ def test_paper_config_gradients_at_the_bench_batch():
             norms = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
             en = float(np.max(np.abs(norms - gd["norms"]) / (gd["norms"] + 1e-6 * gd["norms"].max())))
             err[arith] = (e, abs(float(loss.detach()) - float(gd["loss"])), en)
-            assert err[arith][1] < 1e-3 and e < bound and en < 2e-3, (arith, err[arith])
+            assert err[arith][1] < 1e-3 and e < bound and en < 5e-3, (arith, err[arith])      # observed: 2.9e-6 / 1.6e-5 / 1.3e-5; norms 1.3e-4 / 1.4e-3 / 1.6e-3
     print("paper config, M = 8: (|g - g_fp64| / |g_fp64| on every %dth element, loss error [dB], worst tensor-norm error) %s" % (stride, err))
     assert err["h3"][0] <= 1.1 * err["fp32"][0], err
 
@@ -397,9 +397,11 @@ def test_trajectories_of_the_three_arithmetics():
           runs of the REFERENCE'S OWN fp32 arithmetic land on different sides: the CPU oracle with 8 threads (this fixture) gives
           -0.310169 at step 6, with 16 threads on the GPU box's host -0.306235;
       (b) h3 follows the fp64 trajectory within 1e-3 dB over all 10 steps (observed 1e-5), b6 / fp32 within 8e-3 dB;
-      (c) from the same state, every step's loss agrees within 1e-4 dB and the parameter update within 5 % (observed <= 1.5 %, at the
-          event; 0.1 % otherwise) -- the bound that catches a drift of an arithmetic against the reference's without depending on
-          which side of an event a free-running trajectory falls."""
+      (c) from the same state, every step's loss agrees within 1e-4 dB (observed 4e-6) and the parameter update within 2 % (observed
+          0.2 % for both b6 and h3: the sign noise of Adam on near-zero gradients) -- the bound that catches a drift of an
+          arithmetic against the reference's without depending on which side of an event a free-running trajectory falls.
+    Observed on the MI355X: h3 follows BOTH CPU fixtures within 1.4e-5 dB (the container's CPU-fp32 run is on its side of the event),
+    b6 and the fp32 MFMA within 1.5e-4 dB up to step 5 and 3.9e-3 dB behind it (they follow the GPU box's CPU-fp32 run within 4e-5)."""
     from conv_tasnet_amd.optim import FlatAdam
     from conv_tasnet_amd.train import SyntheticLoader
     g64, g32 = load_golden("paper_traj_fp64"), load_golden("paper_traj_cpu_fp32")
@@ -452,4 +454,4 @@ def test_trajectories_of_the_three_arithmetics():
     assert min(dev[a]["late"] for a in ("fp32", "b6", "h3")) < 2e-4, dev       # at least one arithmetic is on the fixture's side of the event
     assert dev["h3"]["fp64"] < 1e-3 and dev["b6"]["fp64"] < 8e-3 and dev["fp32"]["fp64"] < 8e-3, dev
     for arith in ("b6", "h3"):
-        assert dev[arith]["same_state_loss"] < 1e-4 and dev[arith]["same_state_update"] < 5e-2, (arith, dev[arith])
+        assert dev[arith]["same_state_loss"] < 1e-4 and dev[arith]["same_state_update"] < 2e-2, (arith, dev[arith])
