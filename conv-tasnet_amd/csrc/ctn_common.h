@@ -105,6 +105,14 @@ __device__ __forceinline__ void block_amax_atomic(float v, double* scratch, unsi
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  Give each XCD a contiguous range of LOGICAL ids, so
+// that neighbours in the logical order -- the row tiles of a GEMM that re-read the same activation columns, the two 64-byte halves
+// of a 128-byte line -- are served by one private L2 instead of the fabric.  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // Finalise (mean, rstd) of one utterance from [nparts][2] double partial (sum, sumsq).
 // Every thread of the block returns the same values.  count = Ch*K valid elements.
 template <int NT>

@@ -86,14 +86,6 @@ __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2).  The row tiles that re-read the same
-// activation columns are consecutive tile indices, so give each XCD a contiguous range of tile indices: its private
-// L2 then serves the re-reads instead of the fabric.  Bijective for any grid size; affects speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
 // Operand prologue: gLN(prelu(x)) = gamma*((prelu(x)-mean)*rstd)+beta, folded to one select + one FMA per element:
 //   gs = gamma*rstd, cc = beta - gs*mean  ->  x' = x * (x >= 0 ? gs : gs*alpha) + cc ;  0 for frames k >= K.
 __device__ __forceinline__ float4 pro_apply(float4 v, int k, int K, float g, float b, float alpha, float mean, float rstd) {

@@ -751,20 +751,21 @@ __global__ __launch_bounds__(NTB) void cln_bwd_dx_reg_kernel(const float* __rest
 // ---------------------------------------------------------------------------
 constexpr int C4_NT = 512, C4_FR = 32, C4_NG = C4_NT / (C4_FR / 4);      // 64 channel groups
 
-__device__ __forceinline__ float4 quad_group_sum(float4 v) {              // sum over the 8 channel groups of a wave (lane bits 3..5)
+template <int FR = C4_FR>
+__device__ __forceinline__ float4 quad_group_sum(float4 v) {              // sum over the channel groups of a wave (lane bits above the FR / 4 frame quads)
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
+    for (int o = FR / 4; o < 64; o <<= 1) {
         v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
         v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
     }
     return v;
 }
-// sum of `v` over all 64 channel groups of the workgroup, result for this thread's frame quad in every thread
-template <int NW = C4_NT / 64>
-__device__ __forceinline__ float4 block_group_sum(float4 v, float4 (*sh)[C4_FR / 4], int wave, int q, int lane) {
-    v = quad_group_sum(v);
+// sum of `v` over all channel groups of the workgroup, result for this thread's frame quad in every thread
+template <int NW = C4_NT / 64, int FR = C4_FR>
+__device__ __forceinline__ float4 block_group_sum(float4 v, float4 (*sh)[FR / 4], int wave, int q, int lane) {
+    v = quad_group_sum<FR>(v);
     __syncthreads();                                 // sh may still be read by a previous call
-    if (lane < C4_FR / 4) sh[wave][q] = v;
+    if (lane < FR / 4) sh[wave][q] = v;
     __syncthreads();
     float4 r = sh[0][q];
 #pragma unroll
@@ -775,16 +776,20 @@ __device__ __forceinline__ float4 block_group_sum(float4 v, float4 (*sh)[C4_FR /
     return r;
 }
 
-template <int CPT>
-__global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restrict__ Y, float* __restrict__ Out,
+// (NTB, FR) = (512, 32) or (256, 16): the same channel groups and per-thread work; the small form fits more independent workgroups on a CU
+template <int CPT, int NTB = C4_NT, int FR = C4_FR>
+__global__ __launch_bounds__(NTB) void cln_fwd_v4_kernel(const float* __restrict__ Y, float* __restrict__ Out,
                                                            float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                            int M, int Ch, int K, int Kp, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ alpha_p,
                                                            unsigned* __restrict__ amax_out) {
-    __shared__ float4 sh[C4_NT / 64][C4_FR / 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid & 7, g = tid >> 3;
-    const int kb = Kp / C4_FR;
-    const int m = blockIdx.x / kb, k0 = (blockIdx.x % kb) * C4_FR + 4 * q;
+    constexpr int NW = NTB / 64, NQ = FR / 4, C4_NG = NTB / NQ;
+    static_assert(C4_NG == 64, "64 channel groups");
+    __shared__ float4 sh[NW][NQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid % NQ, g = tid / NQ;
+    const int kb = Kp / FR;
+    const int bx = FR == 32 ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int m = bx / kb, k0 = (bx % kb) * FR + 4 * q;
     float amax = 0.f;
     const bool has_a = alpha_p != nullptr;
     const float al = has_a ? alpha_p[0] : 1.f;
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restri
         v[j] = t;
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    float4 mu = block_group_sum(s, sh, wave, q, lane);
+    float4 mu = block_group_sum<NW, FR>(s, sh, wave, q, lane);
     const float inv = 1.f / (float)Ch;
     mu.x *= inv; mu.y *= inv; mu.z *= inv; mu.w *= inv;
     float4 d2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restri
             d2.x += (v[j].x - mu.x) * (v[j].x - mu.x); d2.y += (v[j].y - mu.y) * (v[j].y - mu.y);
             d2.z += (v[j].z - mu.z) * (v[j].z - mu.z); d2.w += (v[j].w - mu.w) * (v[j].w - mu.w);
         }
-    const float4 var = block_group_sum(d2, sh, wave, q, lane);
+    const float4 var = block_group_sum<NW, FR>(d2, sh, wave, q, lane);
     const float4 rs = make_float4(1.0f / sqrtf(var.x * inv + CTN_EPS), 1.0f / sqrtf(var.y * inv + CTN_EPS),
                                   1.0f / sqrtf(var.z * inv + CTN_EPS), 1.0f / sqrtf(var.w * inv + CTN_EPS));
     if (g == 0) {
@@ -832,13 +837,17 @@ __global__ __launch_bounds__(C4_NT) void cln_fwd_v4_kernel(const float* __restri
         }
     }
     if (amax_out != nullptr)        // h3 arithmetic of the GEMM that reads Out: its maximum per utterance
-        block_amax_atomic<C4_NT>(amax, reinterpret_cast<double*>(&sh[0][0]), amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % kb);
+        block_amax_atomic<NTB>(amax, reinterpret_cast<double*>(&sh[0][0]), amax_out + (size_t)m * CTN_AMAX_SLOTS, bx % kb);
 }
 
 // NTB threads = NTB/8 channel groups.  CPT = 8 at 512 threads needs 161 VGPRs (one workgroup = 2 waves per SIMD) and is
 // still the fastest form for 512 channels: 1024 threads x CPT 4 (4 waves per SIMD) measured 84 us against 55 us, capping
 // the registers at 128 (re-reading dOut in the second phase) 59 us.
-template <int CPT, int NTB>
+// FR = frames per workgroup.  (512 threads, 32 frames) holds ONE workgroup per CU (161 VGPRs x 8 waves): it loads 128 KiB, reduces,
+// then stores 64 KiB, and nothing on the CU overlaps those phases.  (256 threads, 16 frames) has the same channel groups, registers
+// and instruction stream per thread, but three independent workgroups fit a CU; its 64-byte row pieces pair up into whole
+// 128-byte lines with the neighbouring workgroup, which the XCD-contiguous block order keeps on the same L2.
+template <int CPT, int NTB, int FR = C4_FR>
 __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                            float* __restrict__ dY, const float* __restrict__ mean_i,
                                                            const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
@@ -846,12 +855,13 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
                                                            const float* __restrict__ add, const float* __restrict__ relu_ref,
                                                            float* __restrict__ dalpha_part, float* __restrict__ pc,
                                                            unsigned* __restrict__ amax_out) {
-    constexpr int NW = NTB / 64, NG = NTB / (C4_FR / 4);
-    __shared__ float4 sh[NW][C4_FR / 4];
+    constexpr int NW = NTB / 64, NQ = FR / 4, NG = NTB / NQ;
+    __shared__ float4 sh[NW][NQ];
     __shared__ float red[NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid & 7, g = tid >> 3;
-    const int kb = Kp / C4_FR, nblk = M * kb;
-    const int m = blockIdx.x / kb, k0 = (blockIdx.x % kb) * C4_FR + 4 * q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = tid % NQ, g = tid / NQ;
+    const int kb = Kp / FR, nblk = M * kb;
+    const int bx = FR == C4_FR ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, nblk);        // FR 16: the two halves of a 128-byte line on one XCD
+    const int m = bx / kb, k0 = (bx % kb) * FR + 4 * q;
     const bool has_a = alpha_p != nullptr;
     const float al = has_a ? alpha_p[0] : 1.f;
     const size_t off = (size_t)m * Ch * Kp + k0;
@@ -875,17 +885,17 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
         // parameter-gradient partials of channel c over this workgroup's frames: its 4 frames here, the 8 quads by shuffles
         float pg = (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w), pb = (d.x + d.y) + (d.z + d.w);
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64); }
+        for (int o = 1; o < NQ; o <<= 1) { pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64); }
         if (q == 0 && c < Ch) {
-            pc[(size_t)blockIdx.x * Ch + c] = pg;
-            pc[((size_t)nblk + blockIdx.x) * Ch + c] = pb;
+            pc[(size_t)bx * Ch + c] = pg;
+            pc[((size_t)nblk + bx) * Ch + c] = pb;
         }
         yv[j] = y;
         t[j] = make_float4(ga * d.x, ga * d.y, ga * d.z, ga * d.w);
         s1.x += t[j].x; s1.y += t[j].y; s1.z += t[j].z; s1.w += t[j].w;
         s2.x += t[j].x * xh.x; s2.y += t[j].y * xh.y; s2.z += t[j].z * xh.z; s2.w += t[j].w * xh.w;
     }
-    float4 m1 = block_group_sum<NW>(s1, sh, wave, q, lane), m2 = block_group_sum<NW>(s2, sh, wave, q, lane);
+    float4 m1 = block_group_sum<NW, FR>(s1, sh, wave, q, lane), m2 = block_group_sum<NW, FR>(s2, sh, wave, q, lane);
     const float inv = 1.f / (float)Ch;
     m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
     m2.x *= inv; m2.y *= inv; m2.z *= inv; m2.w *= inv;
@@ -923,10 +933,10 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
     }
     if (dalpha_part != nullptr) {
         dal = block_sum<float, NTB>(dal, red);
-        if (tid == 0) dalpha_part[blockIdx.x] = dal;
+        if (tid == 0) dalpha_part[bx] = dal;
     }
     if (amax_out != nullptr)
-        block_amax_atomic<NTB>(amax, reinterpret_cast<double*>(&sh[0][0]), amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % kb);
+        block_amax_atomic<NTB>(amax, reinterpret_cast<double*>(&sh[0][0]), amax_out + (size_t)m * CTN_AMAX_SLOTS, bx % kb);
 }
 
 // per-(m,c) partial of dgamma = sum_k dOut*xh and dbeta = sum_k dOut ; pc[2][rows][Ch], rows >= M (fallback of the v4 kernel)
@@ -1224,6 +1234,11 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
     return CTN_OK;
 }
 
+// frames per workgroup of the cln_*_v4 kernels: 16 (256 threads, three and more workgroups per CU; default since round 4) or 32
+// (512 threads); ctn_tune("cln_fr", 16 | 32).  The backward partial buffers are sized and summed by this count for every kernel
+// of the family.
+int g_ctn_cln_fr = 16;
+
 static bool cln_v4_ok(int Ch, int Kp, const void* a, const void* b, const void* c) {
     return Ch <= 8 * C4_NG && Kp % C4_FR == 0 && aligned16(a) && aligned16(b) && aligned16(c);
 }
@@ -1234,8 +1249,10 @@ int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int
     CTN_REQUIRE(M > 0 && Ch > 0 && K > 0 && Kp >= K, "ctn_cln_fwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     if (cln_v4_ok(Ch, Kp, Y, Out, mean) && aligned16(rstd)) {     // 16-byte accesses along frames (round 2)
-        const dim3 grid((unsigned)(M * (Kp / C4_FR)));
-#define CTN_CLN_FWD4(CPT_) hipLaunchKernelGGL((cln_fwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha, amax_out)
+        const bool small = g_ctn_cln_fr == 16;                     // (Kp % 32 == 0 was checked: 16 divides it)
+        const dim3 grid((unsigned)(M * (Kp / (small ? 16 : C4_FR))));
+#define CTN_CLN_FWD4(CPT_) do { if (small) hipLaunchKernelGGL((cln_fwd_v4_kernel<CPT_, 256, 16>), grid, dim3(256), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha, amax_out); \
+                                else hipLaunchKernelGGL((cln_fwd_v4_kernel<CPT_>), grid, dim3(C4_NT), 0, st, Y, Out, mean, rstd, M, Ch, K, Kp, gamma, beta, alpha, amax_out); } while (0)
         const int cpt = ctn_cdiv(Ch, C4_NG);
         if (cpt <= 1) CTN_CLN_FWD4(1);
         else if (cpt <= 2) CTN_CLN_FWD4(2);
@@ -1261,7 +1278,7 @@ int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int
     return CTN_OK;
 }
 
-int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, CLN_FR); }   // workgroups of the backward kernels (32 frames each)
+int ctn_cln_bwd_blocks(int M, int Kp) { return M * ctn_cdiv(Kp, g_ctn_cln_fr); }   // rows of the parameter-gradient partials
 size_t ctn_cln_bwd_pc_floats(int M, int Ch, int Kp) { return (size_t)2 * ctn_cln_bwd_blocks(M, Kp) * Ch; }
 
 // see include/ctn_hip.h.  pc is [2][ctn_cln_bwd_blocks(M, Kp)][Ch]
@@ -1275,25 +1292,28 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     hipStream_t st = (hipStream_t)stream;
     float* const dap = alpha ? dalpha_part : nullptr;
     const int rows = ctn_cln_bwd_blocks(M, Kp);
-    if (cln_v4_ok(Ch, Kp, dOut, Y, dY) && (!add || aligned16(add)) && (!relu_ref || aligned16(relu_ref))) {
+    if (cln_v4_ok(Ch, Kp, dOut, Y, dY) && Kp % g_ctn_cln_fr == 0 && (!add || aligned16(add)) && (!relu_ref || aligned16(relu_ref))) {
         // one pass: input gradient AND the parameter-gradient partials (dY may alias dOut: each thread reads its elements
         // of dOut before it writes them)
         const dim3 grid((unsigned)rows);
-#define CTN_CLN_BWD4(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, NTB_>), grid, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out)
-        if (Ch <= C4_NG) CTN_CLN_BWD4(1, C4_NT);
-        else if (Ch <= 2 * C4_NG) CTN_CLN_BWD4(2, C4_NT);
-        else if (Ch <= 4 * C4_NG) CTN_CLN_BWD4(4, C4_NT);
-        else CTN_CLN_BWD4(8, C4_NT);
+#define CTN_CLN_BWD4(CPT_) do { if (g_ctn_cln_fr == 16) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, 256, 16>), grid, dim3(256), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out); \
+                                else hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, C4_NT, C4_FR>), grid, dim3(C4_NT), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out); } while (0)
+        if (Ch <= C4_NG) CTN_CLN_BWD4(1);
+        else if (Ch <= 2 * C4_NG) CTN_CLN_BWD4(2);
+        else if (Ch <= 4 * C4_NG) CTN_CLN_BWD4(4);
+        else CTN_CLN_BWD4(8);
 #undef CTN_CLN_BWD4
         CTN_CHECK_LAUNCH("ctn_cln_bwd");
         return CTN_OK;
     }
-    // fallback (very wide layers / unaligned frames): parameter partials first (dY may alias dOut), into the first M rows of pc
+    // fallback (very wide layers / unaligned frames): parameter partials first (dY may alias dOut), into the first M rows of pc;
+    // these kernels work in 32-frame blocks whatever g_ctn_cln_fr is: the partial rows they do not write stay zero
     hipMemsetAsync(pc, 0, sizeof(float) * ctn_cln_bwd_pc_floats(M, Ch, Kp), st);
+    if (dap) hipMemsetAsync(dap, 0, sizeof(float) * (size_t)rows, st);
     hipLaunchKernelGGL(cln_bwd_params_kernel, dim3((unsigned)(M * ctn_cdiv(Ch, ROWS))), dim3(NT), 0, st,
                        dOut, Y, mean, rstd, M, Ch, K, Kp, alpha, pc, rows);
     CTN_CHECK_LAUNCH("ctn_cln_bwd/params");
-    const dim3 grid_r((unsigned)rows);
+    const dim3 grid_r((unsigned)(M * ctn_cdiv(Kp, CLN_FR)));
 #define CTN_CLN_BWD(CPT_, NTB_) hipLaunchKernelGGL((cln_bwd_dx_reg_kernel<CLN_FR, CPT_, NTB_>), grid_r, dim3(NTB_), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap)
     if (Ch <= 32) CTN_CLN_BWD(2, 512);
     else if (Ch <= 64) CTN_CLN_BWD(4, 512);
@@ -1301,7 +1321,6 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
     else if (Ch <= 256) CTN_CLN_BWD(16, 512);
     else if (Ch <= 512) CTN_CLN_BWD(16, 1024);
     else {      // generic kernel; it fills only the first M*ceil(Kp/64) partials of the buffer
-        if (dap) hipMemsetAsync(dap, 0, sizeof(float) * (size_t)rows, st);
         hipLaunchKernelGGL(cln_bwd_dx_kernel, dim3((unsigned)(M * ctn_cdiv(Kp, 64))), dim3(NT), 0, st, dOut, Y, dY, mean, rstd, M,
                            Ch, K, Kp, gamma, alpha, add, relu_ref, dap);
     }

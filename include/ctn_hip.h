@@ -88,7 +88,8 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * own); "b3_wgrad_blocks", "wgrad_blocks": target workgroups per weight-gradient launch (split-bf16 / fp32 MFMA);
  * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE); "b3_ws" 0|1 (default 0): run the h3 forward /
  * input-gradient GEMMs on the wave-specialised persistent kernel (csrc/ctn_gemm_ws.h; same values, measured slower: kept as a tested
- * experiment), "b3_ws_blocks": its workgroup count.  Defaults are the measured best. */
+ * experiment), "b3_ws_blocks": its workgroup count; "cln_fr" 16|32: frames per workgroup of the channel-wise LayerNorm backward
+ * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()).  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
  *   3 = "h3" (default): the GEMMs of the composite stacks (ctn_tcn_*) run on the ctn_*_h3 entry points below -- two fp16 pieces
@@ -284,7 +285,8 @@ int ctn_cln_fwd(const float* Y, float* Out, float* mean, float* rstd, int M, int
                 const float* gamma, const float* beta, const float* alpha, unsigned* amax_out, void* stream);
 /* dY = [cLN/PReLU backward of dOut  (+ add)] masked by (relu_ref > 0) when relu_ref != NULL -- and, in the same pass, the
  * parameter-gradient partials: pc [2][ctn_cln_bwd_blocks(M,Kp)][Ch] (ctn_cln_bwd_pc_floats() floats: dgamma, dbeta of every
- * 32-frame workgroup) and dalpha_part [ctn_cln_bwd_blocks(M,Kp)]; ctn_cln_bwd_finalize sums them in fixed order.
+ * workgroup's 16 frames -- 32 with ctn_tune("cln_fr", 32) --) and dalpha_part [ctn_cln_bwd_blocks(M,Kp)]; ctn_cln_bwd_finalize
+ * sums them in fixed order.  Size both with the functions below AFTER any ctn_tune("cln_fr", ...).
  * amax_out != NULL: [M][CTN_AMAX_SLOTS], receives max |dY[m]| (h3 section). */
 int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean, const float* rstd,
                 int M, int Ch, int K, int Kp, const float* gamma, const float* alpha,
