@@ -45,6 +45,8 @@ def apply(cfg):
             ops._FWD_DUAL = bool(int(v))
         elif k == "cln_side":
             ops._CLN_SIDE = bool(int(v))
+        elif k == "small_side":
+            ops._SMALL_SIDE = bool(int(v))
         elif k == "hp":                     # 1: run the step's main chain on a HIGH-priority stream (the weight-gradient stream stays normal)
             global HP
             HP = bool(int(v))

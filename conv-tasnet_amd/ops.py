@@ -310,6 +310,18 @@ def _wgrad_async(dOut, X, R, Cn, K, out, pro=None, first=None, first_inputs=(), 
         t.record_stream(side)        # the caching allocator must not hand these out before the side stream is done
 
 
+_SMALL_SIDE = os.environ.get("CTN_SMALL_WGRAD_SIDE", "1") != "0"
+
+
+def _wgrad_small(dOut, X, R, Cn, K, sink):
+    """Weight gradient of a front-end / back-end 1x1 conv: on the side stream when it lands in a gradient sink (nothing on
+    the current stream reads it before join_side_stream()), on the current stream otherwise (autograd consumes the result)."""
+    if sink is not None and _SIDE_ENABLED and _SMALL_SIDE and X.is_cuda:
+        _wgrad_async(dOut, X, R, Cn, K, sink)
+        return None
+    return pw_wgrad(dOut, X, R, Cn, K, out=sink)
+
+
 def _workspace(nbytes, device, tag):
     """Scratch that is fully consumed inside one C call (stream-ordered), so one buffer per tag is enough."""
     key = (device, tag)
@@ -441,7 +453,7 @@ class Frontend(torch.autograd.Function):
         if sU is not None:
             _claim_sinks(U)
         dy0, _ = pw_gemm(Wb, dx0, N, B, K, trans_w=True)
-        dWb = pw_wgrad(dx0, y0, B, N, K, out=sWb)
+        dWb = _wgrad_small(dx0, y0, B, N, K, sWb)
         add = None if dw_dec is None else _c(dw_dec)
         g, dg0, db0, _ = cln_bwd(dy0, w, mean0, rstd0, g0, None, K, add=add, relu_ref=w)
         dU = pw_wgrad(g, xcol, N, L, K, out=sU)
@@ -1042,12 +1054,12 @@ class Backend(torch.autograd.Function):
         sWm, sV = ctx.sinks
         if sWm is not None:
             _claim_sinks(Wm)
-        dV = pw_wgrad(dfr, sw.view(M * C, N, Kp), L, N, K, out=sV)
+        dV = _wgrad_small(dfr, sw.view(M * C, N, Kp), L, N, K, sV)
         dw = torch.empty((M, N, Kp), dtype=F32, device=dev)
         lib.call("ctn_mask_apply_bwd", _p(dsw), _p(score), _p(w), _p(dsw), _p(dw), M, C, N, Kp, int(softmax), _stream())
         dscore = dsw.view(M, CN, Kp)
         dx, _ = pw_gemm(Wm, dscore, B, CN, K, trans_w=True)
-        dWm = pw_wgrad(dscore, x, CN, B, K, out=sWm)
+        dWm = _wgrad_small(dscore, x, CN, B, K, sWm)
         return (dx, dw, None if sWm is not None else dWm.view(CN, B, 1), None if sV is not None else dV,
                 None, None, None, None)
 
