@@ -9,7 +9,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -amd
 python conv-tasnet_amd/_build.py > /dev/null
 OBJS=$(ls conv-tasnet_amd/csrc/build/*.o | grep -v ctn_gemm.o)
 for tag in $TAGS; do
-  ( $HIPCC $FLAGS -DCTN_EXP_B3_$tag -c conv-tasnet_amd/csrc/ctn_gemm.hip -o /tmp/lab_objs/ctn_gemm_$tag.o && \
+  defs=$(echo $tag | sed 's/+/ -DCTN_EXP_B3_/g')          # "A+B" builds with both hooks
+  ( $HIPCC $FLAGS -DCTN_EXP_B3_$defs $EXTRA_DEFS -c conv-tasnet_amd/csrc/ctn_gemm.hip -o /tmp/lab_objs/ctn_gemm_$tag.o && \
     $HIPCC --offload-arch=gfx950 -shared -fPIC -o benchmarks/lab_gemm_$tag.so $OBJS /tmp/lab_objs/ctn_gemm_$tag.o ) &
 done
 wait

@@ -19,7 +19,7 @@
 // ---- measurement hook (bench.py's roofline leg): HIP events around every launch group of the composite stacks, on the stream
 // the group is launched to.  Off by default (no events, no overhead); ctn_probe_enable(1) starts a recording, ctn_probe_read
 // waits for the recorded events, returns (family id, microseconds) per launch group in issue order and ends the recording.
-enum { F_K1 = 0, F_K2, F_K3, F_B1, F_B2, F_B3, F_B4, F_B5, F_B6, F_FIN, F_PREP, F_CLN_FWD, F_CLN_BWD, F_TAPS, F_COUNT };
+enum { F_K1 = 0, F_K2, F_K3, F_B1, F_B2, F_B3, F_B4, F_B5, F_B6, F_FIN, F_PREP, F_CLN_FWD, F_CLN_BWD, F_TAPS, F_WFLUSH, F_COUNT };
 namespace {
 struct ProbeRec { int fam; hipEvent_t e0, e1; };
 std::vector<ProbeRec> g_probe;          // guarded by g_probe_mu: a second host thread that drives the library while a recording is
@@ -169,7 +169,7 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.da1p = o; o += (size_t)nblocks * w.da1p_slot;
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
     w.slab_bytes = s1 > s2 ? s1 : s2;
-    w.slab = o; o += align256(w.slab_bytes);
+    w.slab = o; o += 2 * align256(w.slab_bytes);          // two: a chained weight gradient writes one while the next launch sums the other
     w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);         // [nblocks][w2 operand (H rows) | w1 operand (B rows)], b3 pieces
     w.gb = o; o += align256((size_t)nblocks * 2 * sizeof(float));   // h3: {max |gamma2|, max |beta2|} per block
     w.amax = o; o += align256((size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block and utterance
@@ -291,7 +291,10 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
     char* const ws = (char*)workspace;
     float* const dn2 = (float*)(ws + w.dn2);
     double* const s2p = (double*)(ws + w.s2p);
-    void* const slab = ws + w.slab;
+    // chained weight gradients (ctn_common.h): each launch's slabs are summed inside the next launch of the weight-gradient stream
+    void* const slabs[2] = {ws + w.slab, ws + w.slab + align256(w.slab_bytes)};
+    CtnWgradChain chain;
+    int nwg = 0;
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp;
     void* const wst = side_stream ? side_stream : stream;       // where the weight gradients (and parameter-gradient sums) go
     int rc;
@@ -336,8 +339,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         else rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         if (rc) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, ady, ad, gb + 2 * i, slab, w.slab_bytes, wst));
-        else rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slab, w.slab_bytes, wst));
+        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, ady, ad, gb + 2 * i, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+        else rc = PROBED(F_B2, wst, ctn_pw_wgrad_chained(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         if (rc) return rc;
         // gLN2 <- PReLU2 <- depthwise <- gLN1 output in one pass, then gLN1 + PReLU1 backward in place
         rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
@@ -352,8 +355,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         // optimiser: second stream
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         auto wgrad1 = [&]() -> int {
-            if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slab, w.slab_bytes, wst));
-            return PROBED(F_B6, wst, ctn_pw_wgrad(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
+            if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3_chained(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+            return PROBED(F_B6, wst, ctn_pw_wgrad_chained(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         };
         auto finalize = [&](void* st) -> int {
             return PROBED(F_FIN, st, ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st));
@@ -372,6 +375,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = finalize(stream))) return rc;
         }
     }
+    if ((rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
     // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
     // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)
     if (side_stream && !(flags & 1) && (rc = ctn_stream_order(side_stream, stream))) return rc;
@@ -402,7 +406,7 @@ ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.dap = o; o += (size_t)nblocks * 2 * w.dap_slot;
     const size_t s1 = ctn_pw_wgrad_workspace(M, H, B, Kp), s2 = ctn_pw_wgrad_workspace(M, B, H, Kp);
     w.slab_bytes = s1 > s2 ? s1 : s2;
-    w.slab = o; o += align256(w.slab_bytes);
+    w.slab = o; o += 2 * align256(w.slab_bytes);          // two: a chained weight gradient writes one while the next launch sums the other
     w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);
     w.amax = o; o += align256((size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block
     w.total = o;
@@ -509,7 +513,10 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     float* const dn2 = (float*)(ws + w.dn2);
     float* const dd = (float*)(ws + w.dd);
     float* const dn1 = (float*)(ws + w.dn1);
-    void* const slab = ws + w.slab;
+    // chained weight gradients (ctn_common.h): each launch's slabs are summed inside the next launch of the weight-gradient stream
+    void* const slabs[2] = {ws + w.slab, ws + w.slab + align256(w.slab_bytes)};
+    CtnWgradChain chain;
+    int nwg = 0;
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
     void* const wst = side_stream ? side_stream : stream;
     int rc;
@@ -551,8 +558,8 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream));
         if (rc) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, ady, an, nullptr, slab, w.slab_bytes, wst));
-        else rc = PROBED(F_B2, wst, ctn_pw_wgrad(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
+        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, ady, an, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+        else rc = PROBED(F_B2, wst, ctn_pw_wgrad_chained(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         if (rc) return rc;
         if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, nullptr, stream)))) return rc;
         if ((rc = PROBED(F_B3, stream, ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
@@ -565,8 +572,8 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
         if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst)))) return rc;
         auto wgrad1 = [&]() -> int {
-            if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slab, w.slab_bytes, wst));
-            return PROBED(F_B6, wst, ctn_pw_wgrad(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slab, w.slab_bytes, wst));
+            if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3_chained(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+            return PROBED(F_B6, wst, ctn_pw_wgrad_chained(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         };
         if (side_stream && (rc = wgrad1())) return rc;
         if (h3) rc = PROBED(F_B5, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i + 1) * slot, dh1, dx, M, B, H, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy,
@@ -576,6 +583,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if (rc) return rc;
         if (!side_stream && (rc = wgrad1())) return rc;
     }
+    if ((rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
     // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
     // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)
     if (side_stream && !(flags & 1) && (rc = ctn_stream_order(side_stream, stream))) return rc;

@@ -37,6 +37,21 @@ void ctn_set_error(const char* fmt, ...);
 static inline int ctn_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long ctn_cdivll(long long a, long long b) { return (a + b - 1) / b; }
 
+// ---- chained weight gradients (library-internal: the composite stacks of ctn_block.hip call these, ctn_gemm.hip defines them) ----
+// A chained launch leaves its split-K slabs unsummed and records them in *chain; the next chained launch ON THE SAME STREAM sums
+// them inside its own kernel (same addition order as slab_reduce_kernel: bitwise the un-chained result) and records its own.
+// Every launch of a chain needs a slab buffer different from the pending one (alternate between two);
+// ctn_wgrad_chain_flush() sums what is still pending with a slab_reduce launch.  chain == nullptr: the plain entry point.
+struct CtnWgradChain { const float* slab = nullptr; float* out = nullptr; long long n = 0; int nsplit = 0; };
+int ctn_pw_wgrad_chained(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                         const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                         void* workspace, size_t workspace_bytes, void* stream, CtnWgradChain* chain);
+int ctn_pw_wgrad_h3_chained(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                            const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                            const unsigned* g_amax, const unsigned* x_amax, const float* pro_gbmax,
+                            void* workspace, size_t workspace_bytes, void* stream, CtnWgradChain* chain);
+int ctn_wgrad_chain_flush(CtnWgradChain* chain, void* stream);
+
 #ifdef __HIPCC__
 // ---- wave64 / block reductions ---------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -661,7 +661,9 @@ static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int*
 // Library switches for in-process A/B runs and the test-suite (process-global: call them from the thread that issues the work,
 // between steps).  Keys: "arith" (3 h3, 2 b6, 0 fp32 MFMA), "b3_tile" (0 128x128, 1 128x64, 2 256x64: tile of the split-bf16
 // forward / input-gradient kernels), "b3_tile_k3" (the same for the prologue + residual form), "b3_wgrad_blocks" / "wgrad_blocks"
-// (target workgroups per weight-gradient launch, split-bf16 / fp32), "pw_tile" (fp32 forward tile id 0..3, -1 = default).
+// (target workgroups per weight-gradient launch, split-bf16 / fp32), "pw_tile" (fp32 forward tile id 0..3, -1 = default),
+// "wgrad_chain" (below).
+static int g_ctn_wgrad_chain = 1;        // ctn_tune("wgrad_chain", 0): every weight gradient sums its own slabs (a slab_reduce launch each)
 int ctn_tune(const char* key, int value) {
     if (!key) return CTN_ERR_ARG;
     if (!strcmp(key, "pw_tile") && value >= -1 && value <= 3) g_ctn_tile_override = value;
@@ -673,6 +675,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "cln_fr") && (value == 16 || value == 32)) g_ctn_cln_fr = value;
     else if (!strcmp(key, "b3_ws") && (value == 0 || value == 1)) g_ctn_b3_ws = value;
     else if (!strcmp(key, "b3_ws_blocks") && value >= 1) g_ctn_b3_ws_blocks = value;
+    else if (!strcmp(key, "wgrad_chain") && (value == 0 || value == 1)) g_ctn_wgrad_chain = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }
@@ -691,8 +694,44 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp) {
 int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
                  const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
                  void* workspace, size_t workspace_bytes, void* stream) {
+    return ctn_pw_wgrad_chained(dOut, X, dW, M, R, Cn, K, Kp, pro_gamma, pro_beta, pro_alpha, pro_ms, workspace, workspace_bytes, stream, nullptr);
+}
+}  // extern "C"
+
+// ---- chained weight gradients (ctn_common.h) -------------------------------------------------------------------------------
+// The split-K slabs of one launch are summed by the NEXT weight-gradient launch of the same stream (its workgroups do it while
+// their first tiles are in flight) instead of a slab_reduce launch of their own: one launch less per weight gradient and the
+// reduction off the stream's critical path.  ctn_wgrad_chain_flush() sums what is still pending.
+static void chain_attach(WgArgs& a, const CtnWgradChain* chain) {
+    if (chain && chain->slab) { a.prev_slab = chain->slab; a.prev_out = chain->out; a.prev_n = chain->n; a.prev_nsplit = chain->nsplit; }
+}
+
+static int chain_finish(const WgArgs& a, int ns, float* dW, CtnWgradChain* chain, hipStream_t st, const char* fn) {
+    const long long nn = (long long)a.R * a.Cn;
+    if (chain) {
+        chain->slab = a.slab; chain->out = dW; chain->n = nn; chain->nsplit = ns;
+        return CTN_OK;
+    }
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, st, a.slab, ns, nn, dW);
+    CTN_CHECK_LAUNCH(fn);
+    return CTN_OK;
+}
+
+int ctn_wgrad_chain_flush(CtnWgradChain* chain, void* stream) {
+    if (!chain || !chain->slab) return CTN_OK;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(chain->n / 4, NT)), dim3(NT), 0, (hipStream_t)stream, chain->slab, chain->nsplit,
+                       chain->n, chain->out);
+    *chain = CtnWgradChain{};
+    CTN_CHECK_LAUNCH("ctn_wgrad_chain_flush");
+    return CTN_OK;
+}
+
+int ctn_pw_wgrad_chained(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                         const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                         void* workspace, size_t workspace_bytes, void* stream, CtnWgradChain* chain) {
     int rc = check_common("ctn_pw_wgrad", dW, X, (const float*)dOut, M, R, Cn, K, Kp);
     if (rc) return rc;
+    if (!g_ctn_wgrad_chain && chain) { if ((rc = ctn_wgrad_chain_flush(chain, stream))) return rc; chain = nullptr; }
     CTN_REQUIRE(!pro_ms || (pro_gamma && pro_beta && pro_alpha), "ctn_pw_wgrad: incomplete prologue arguments");
     WgArgs a{};
     a.dOut = dOut; a.X = X; a.slab = (float*)workspace; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
@@ -704,13 +743,13 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
             ctn_set_error("ctn_pw_wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
             return CTN_ERR_WORKSPACE;
         }
+        CTN_REQUIRE(!chain || chain->slab != a.slab, "ctn_pw_wgrad: a chained launch needs a slab buffer of its own");
+        chain_attach(a, chain);
         const int ns = ctn_b3_launch_wgrad(arith_np(), a, pro_ms != nullptr, (hipStream_t)stream);
         CTN_CHECK_LAUNCH("ctn_pw_wgrad");
-        const long long nn = (long long)R * Cn;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);
-        CTN_CHECK_LAUNCH("ctn_pw_wgrad/reduce");
-        return CTN_OK;
+        return chain_finish(a, ns, dW, chain, (hipStream_t)stream, "ctn_pw_wgrad/reduce");
     }
+    if ((rc = ctn_wgrad_chain_flush(chain, stream))) return rc;        // the fp32-MFMA kernels do not chain
     int wt;
     wgrad_plan(M, R, Cn, Kp, &wt, &a.chunk, &a.chunks_per_m);
     a.tiles_r = ctn_cdiv(R, wt); a.tiles_c = ctn_cdiv(Cn, wt);
@@ -736,6 +775,7 @@ int ctn_pw_wgrad(const float* dOut, const float* X, float* dW, int M, int R, int
     return CTN_OK;
 }
 
+extern "C" {
 // ---- h3 arithmetic: explicit entry points (independent of ctn_tune("arith")); see include/ctn_hip.h ------------------------------
 size_t ctn_split_h3_bytes(int R, int Cn) { return ctn_b3_planes_bytes(4, R, Cn); }
 
@@ -816,8 +856,18 @@ int ctn_pw_wgrad_h3(const float* dOut, const float* X, float* dW, int M, int R, 
                     const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
                     const unsigned* g_amax, const unsigned* x_amax, const float* pro_gbmax,
                     void* workspace, size_t workspace_bytes, void* stream) {
+    return ctn_pw_wgrad_h3_chained(dOut, X, dW, M, R, Cn, K, Kp, pro_gamma, pro_beta, pro_alpha, pro_ms, g_amax, x_amax, pro_gbmax, workspace,
+                                   workspace_bytes, stream, nullptr);
+}
+}  // extern "C"
+
+int ctn_pw_wgrad_h3_chained(const float* dOut, const float* X, float* dW, int M, int R, int Cn, int K, int Kp,
+                            const float* pro_gamma, const float* pro_beta, const float* pro_alpha, const float* pro_ms,
+                            const unsigned* g_amax, const unsigned* x_amax, const float* pro_gbmax,
+                            void* workspace, size_t workspace_bytes, void* stream, CtnWgradChain* chain) {
     int rc = check_common("ctn_pw_wgrad_h3", dW, X, (const float*)dOut, M, R, Cn, K, Kp);
     if (rc) return rc;
+    if (!g_ctn_wgrad_chain && chain) { if ((rc = ctn_wgrad_chain_flush(chain, stream))) return rc; chain = nullptr; }
     CTN_REQUIRE(R >= 32 && Cn >= 32, "ctn_pw_wgrad_h3: both sides >= 32");
     CTN_REQUIRE(g_amax && x_amax, "ctn_pw_wgrad_h3: the operands' maxima are required");
     CTN_REQUIRE(!pro_ms || (pro_gamma && pro_beta && pro_alpha && pro_gbmax), "ctn_pw_wgrad_h3: incomplete prologue arguments");
@@ -831,11 +881,9 @@ int ctn_pw_wgrad_h3(const float* dOut, const float* X, float* dW, int M, int R, 
         ctn_set_error("ctn_pw_wgrad_h3: workspace too small (%zu < %zu)", workspace_bytes, need);
         return CTN_ERR_WORKSPACE;
     }
+    CTN_REQUIRE(!chain || chain->slab != a.slab, "ctn_pw_wgrad_h3: a chained launch needs a slab buffer of its own");
+    chain_attach(a, chain);
     const int ns = ctn_b3_launch_wgrad(4, a, pro_ms != nullptr, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_wgrad_h3");
-    const long long nn = (long long)R * Cn;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ctn_cdivll(nn / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a.slab, ns, nn, dW);
-    CTN_CHECK_LAUNCH("ctn_pw_wgrad_h3/reduce");
-    return CTN_OK;
+    return chain_finish(a, ns, dW, chain, (hipStream_t)stream, "ctn_pw_wgrad_h3/reduce");
 }
-}  // extern "C"

@@ -356,11 +356,16 @@ template <int AR, int PRO>
 __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     constexpr int NP = Ar<AR>::NP;
     constexpr int PLANE = BM * XPA, STAGE = NP * PLANE;       // bf16 elements: one piece plane, all pieces of one operand
-    __shared__ __attribute__((aligned(16))) __bf16 Ap[2 * STAGE];          // [stage][piece][BM][XPA]   (NP = 3: 2 x 60 KiB)
-    __shared__ __attribute__((aligned(16))) __bf16 Bp[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) __bf16 smem[4 * STAGE];        // (h3: 80 KiB, b6: 120 KiB)
+    __bf16* const Ap = smem;                                               // [stage][piece][BM][XPA]
+    __bf16* const Bp = smem + 2 * STAGE;
+    static_assert(sizeof(smem) >= 32 * 128 * sizeof(float4), "the chained slab reduction stages 32 x 128 float4 in this buffer");
     __shared__ double red[WNT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
+#ifdef CTN_EXP_B3_WGNULL
+    if (a.R > 0) return;
+#endif
     // XCD-aware order: the output tiles of one (utterance, chunk) split read the same activation rows -- give them
     // consecutive logical ids, i.e. the same XCD and its L2 (dealt round-robin they land on 8 different L2s and every
     // operand byte comes from HBM once per tile: 208 MB instead of 79 MB per launch at the paper shapes)
@@ -410,6 +415,9 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     auto load_regs = [&](int kt, float4 (&qa)[2], float4 (&qb)[2]) {
         const int k = kb + kt * XK + kq;
         const unsigned oob = k < ke ? 0u : 0x80000000u;
+#ifdef CTN_EXP_B3_WGNOLOAD
+        if (kt > 2) return;
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (tid >> 3) + 64 * j;
@@ -419,9 +427,18 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     };
     auto write_one = [&](__bf16* P, int row, const float4& v, float sc, auto prescaled) {
         bf16x4 q[NP];
+#ifdef CTN_EXP_B3_WGNOSPLIT
+        q[0] = __builtin_bit_cast(bf16x4, make_float2(v.x, v.y));
+        q[NP - 1] = __builtin_bit_cast(bf16x4, make_float2(v.z, v.w));
+#else
         split_x4<AR, decltype(prescaled)::value>(v, q, sc);
+#endif
+#ifndef CTN_EXP_B3_WGNOWRITE
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(P + p * PLANE + row * XPA + kq) = q[p];
+#else
+        if (q[0][0] == (__bf16)123.f) *reinterpret_cast<bf16x4*>(P + row * XPA + kq) = q[1];
+#endif
     };
     auto write_lds = [&](int kt, int stage, const float4 (&qa)[2], const float4 (&qb)[2]) {
 #pragma unroll
@@ -446,6 +463,9 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     auto compute = [&](int stage) {
         const __bf16* const As = Ap + stage * STAGE;
         const __bf16* const Bs = Bp + stage * STAGE;
+#ifdef CTN_EXP_B3_WGNOCOMPUTE
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[2][NP], bfr[NP];
@@ -456,8 +476,13 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
                     af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PLANE + (wm * 64 + i * 32 + l31) * XPA + ks * 16 + lhi * 8);
                 bfr[p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLANE + (wn * 32 + l31) * XPA + ks * 16 + lhi * 8);
             }
+#ifdef CTN_EXP_B3_WGNOMFMA
+#pragma unroll
+            for (int p = 0; p < NP; ++p) asm volatile("" :: "v"(af[0][p]), "v"(af[1][p]), "v"(bfr[p]));
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i) mfma_pieces<AR>(acc[i], acc2[Ar<AR>::W2 ? i : 0], af[i], bfr);
+#endif
         }
     };
     // Register ring of PF k-tiles: at the top of iteration kt, LDS stage kt % 2 holds tile kt, ring slots (kt + 1 .. kt + PF - 1)
@@ -467,10 +492,52 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
     // (Round 3, b6: running the two halves of each barrier interval -- MFMAs of tile kt, split of tile kt + 1 -- in opposite
     // order on waves 4-7, so that each wave's VALU half sits beside its SIMD partner's MFMA half, measured SLOWER: 48.7 vs
     // 44.9 us alone, 13.71 vs 13.43 ms per step; profiles/README.md.)
+    // Chained launches: this grid also sums the slabs of the previous weight gradient of its stream (complete: stream order).
+    // Workgroup b owns float4s [b * per, (b + 1) * per) of that gradient; per batch of 32 slabs four thread groups load eight
+    // slabs each (loads in flight beside this launch's first three k-tiles), exchange them through LDS, and threads 0-127 add
+    // them in slab order -- the sum sequence of slab_reduce_kernel, bit for bit.
+    const bool chained = a.prev_slab != nullptr;
+    const long long pn4 = a.prev_n >> 2;
+    const long long pper = chained ? (pn4 + gridDim.x - 1) / gridDim.x : 0;
+    const long long plo = (long long)blockIdx.x * pper, phi = plo + pper < pn4 ? plo + pper : pn4;
+    const int pf = tid & 127, pg = tid >> 7;
+    float4 pv[8];
+    auto prev_load = [&](long long base, int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int sl = k0 + 8 * pg + j;
+            pv[j] = (base + pf < phi && sl < a.prev_nsplit) ? *reinterpret_cast<const float4*>(a.prev_slab + ((size_t)sl * pn4 + base + pf) * 4)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto prev_sum = [&](float4& s) {
+        float4* const L = reinterpret_cast<float4*>(smem);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) L[(8 * pg + j) * 128 + pf] = pv[j];
+        __syncthreads();
+        if (pg == 0) {
+#pragma unroll 8
+            for (int sl = 0; sl < 32; ++sl) { const float4 v = L[sl * 128 + pf]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        }
+        __syncthreads();
+    };
+    if (chained && plo < phi) prev_load(plo, 0);
     if (nk > 0) {
         load_regs(0, ra[0], rb[0]);
         if (nk > 1) load_regs(1, ra[1], rb[1]);
         if (nk > 2) load_regs(2, ra[2], rb[2]);
+    }
+    if (chained) {
+        for (long long base = plo; base < phi; base += 128) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k0 = 0; k0 < a.prev_nsplit; k0 += 32) {
+                if (base != plo || k0 != 0) prev_load(base, k0);
+                prev_sum(s);
+            }
+            if (pg == 0 && base + pf < phi) *reinterpret_cast<float4*>(a.prev_out + (base + pf) * 4) = s;
+        }
+    }
+    if (nk > 0) {
         write_lds(0, 0, ra[0], rb[0]);
         __syncthreads();
     }
@@ -479,9 +546,30 @@ __global__ __launch_bounds__(WNT, 2) void pw_wgrad_b3_kernel(WgArgs a) {
         for (int u = 0; u < 6; ++u) {
             const int kt = kt0 + u;
             if (kt < nk) {
-                if (kt + PF < nk) load_regs(kt + PF, ra[u % PF], rb[u % PF]);          // slot of tile kt: already in LDS
+                // One scheduling region per k-tile, no branch inside: loads past the chunk end read 0 (out-of-range offset), the
+                // split after the last k-tile lands in the stage nobody reads again.  The group barriers hand the scheduler
+                // the order of a software pipeline -- first-step fragments and the global loads up front, then every MFMA
+                // followed by its share of the NEXT tile's split (VALU) and, in the first half, one second-step fragment read:
+                // the split runs in the shadow of the matrix pipe instead of after it (alone 33.8 -> 31.6 us dW1, 37.1 -> 35.2
+                // dW2; step -1.1 %; profiles/README.md r04_e).
+                load_regs(kt + PF, ra[u % PF], rb[u % PF]);           // slot of tile kt: already in LDS
                 compute(u % 2);
-                if (kt + 1 < nk) write_lds(kt + 1, (u + 1) % 2, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                write_lds(kt + 1, (u + 1) % 2, ra[(u + 1) % PF], rb[(u + 1) % PF]);
+                constexpr int VG = PRO == PRO_PRELU_NORM ? 10 : 5;    // VALU instructions per MFMA gap (64 / 120 per k-tile and wave)
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VG, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VG, 0);
+                }
                 __syncthreads();
             }
         }

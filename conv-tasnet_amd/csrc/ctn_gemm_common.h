@@ -229,6 +229,9 @@ struct WgArgs {
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; const float* pro_ms;  // [M,2]
     // h3 arithmetic: [M][CTN_AMAX_SLOTS] max |dOut[m]| / max |X[m]| (as stored), {max |gamma|, max |beta|} of the prologue
     const unsigned* g_amax; const unsigned* x_amax; const float* pro_gbmax;
+    // chained launches (ctn_wgrad_chain, ctn_common.h): the slabs of the PREVIOUS weight gradient on this stream, summed by this
+    // launch's workgroups while their first tiles are in flight (nullptr: nothing pending)
+    const float* prev_slab; float* prev_out; long long prev_n; int prev_nsplit;
 };
 
 

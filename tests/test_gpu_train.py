@@ -91,6 +91,38 @@ def test_bucketed_backward_equals_the_single_call(norm, causal, side):
         ops._SIDE_ENABLED = saved_side
 
 
+@pytest.mark.parametrize("side", [True, False])
+@pytest.mark.parametrize("norm,causal", [("gLN", False), ("cLN", True)])
+def test_chained_weight_gradients_equal_the_unchained(norm, causal, side):
+    """Inside the composite stacks the split-K slabs of a weight gradient are summed by the next weight-gradient launch of the
+    stream (ctn_tune("wgrad_chain", 1), the default) instead of a slab_reduce launch of their own: the same additions in the same
+    order, so every gradient must be BITWISE the un-chained one's -- at widths where the split kernels run (B = 64, H = 128), an
+    odd number of blocks per call, with the weight gradients on the second stream and on the main one."""
+    from conv_tasnet_amd import ops
+    torch.manual_seed(5)
+    m = ctn.ConvTasNet(64, 20, 64, 128, 3, 3, 1, 2, norm_type=norm, causal=causal).to(DEV)
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    mix, lens, src = O.synth_batch(41, 3, 4005)
+    mix, lens, src = mix.to(DEV), lens.to(DEV), src.to(DEV)
+    saved_side = ops._SIDE_ENABLED
+    ops._SIDE_ENABLED = side
+    try:
+        grads = []
+        for chain in (0, 1, 1):
+            ctn.lib.call("ctn_tune", b"wgrad_chain", chain)
+            opt.zero_grad()
+            ctn.cal_loss(src, m(mix), lens)[0].backward()
+            ops.join_side_stream(opt.flat_grads.device)
+            torch.cuda.synchronize()
+            grads.append(opt.flat_grads.clone())
+        assert float(grads[0].abs().max()) > 0
+        assert torch.equal(grads[0], grads[1]), "%d gradient elements differ" % int((grads[0] != grads[1]).sum())
+        assert torch.equal(grads[1], grads[2])
+    finally:
+        ctn.lib.call("ctn_tune", b"wgrad_chain", 1)
+        ops._SIDE_ENABLED = saved_side
+
+
 def test_flatadam_state_interchanges_with_torch_adam():
     g, m, batches = _traj_setup()
     opt = FlatAdam(m.parameters(), lr=1e-3)
@@ -414,12 +446,13 @@ def test_library_probe_brackets_every_launch_group_of_the_stacks():
     # per block: K1 K2 K3 forward (each twice when the forward pass runs as two half-batch chains); B1 B2 B3 B4 B5 B6 finalize
     # backward; plus the weight preparation launches
     ids = [fam[i] for i in range(n)]
-    assert n >= 6 * 10 and all(0 <= f <= 13 for f in ids) and all(us[i] > 0 for i in range(n))
+    assert n >= 6 * 10 and all(0 <= f <= 14 for f in ids) and all(us[i] > 0 for i in range(n))
     chains = 2 if (ops._SIDE_ENABLED and ops._FWD_DUAL) else 1
     for f in (0, 1, 2):
         assert ids.count(f) == 6 * chains, (f, ids.count(f))
     for f in (3, 4, 5, 6, 7, 8, 9):
         assert ids.count(f) == 6, (f, ids.count(f))
+    assert ids.count(14) >= 1           # chained weight gradients: one slab_reduce per stack call (the last launch's slabs)
     assert ctn.lib.load().ctn_probe_read(fam, us, 512) == 0         # recording ended
     m(mix.to(DEV))
     assert ctn.lib.load().ctn_probe_read(fam, us, 512) == 0         # and off
