@@ -220,17 +220,17 @@ def family_table(probe, stack, cfg, K, steps):
         1: ("K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)" if gln else "K2 dw_fwd (depthwise)", None, t4 * 2 * H),
         2: ("K3 1x1 H->B (gLN prologue + residual)" if gln else "K3 1x1 H->B + residual", (M, B, H), t4 * (H + 2 * B)),
         3: ("B1 input gradient W2^T.dout (+ gLN backward sums)" if gln else "B1 input gradient W2^T.dout", (M, H, B), t4 * (B + (2 if gln else 1) * H)),
-        4: ("B2 weight gradient dW2 (gLN prologue; + slab sums of the previous weight gradient)" if gln else "B2 weight gradient dW2 (+ slab sums of the previous weight gradient)", (M, B, H), t4 * (B + H)),
+        4: ("B2 weight gradient dW2 (gLN prologue) + slab_reduce" if gln else "B2 weight gradient dW2 + slab_reduce", (M, B, H), t4 * (B + H)),
         5: ("B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)" if gln else "B3 dw_bwd (depthwise^T)", None, t4 * (4 if gln else 3) * H),
         6: ("B4 gln_prelu_bwd", None, t4 * 3 * H),
         7: ("B5 input gradient W1^T.dh1 + dout", (M, B, H), t4 * (H + 2 * B)),
-        8: ("B6 weight gradient dW1 (+ slab sums of the previous weight gradient)", (M, H, B), t4 * (B + H)),
+        8: ("B6 weight gradient dW1 + slab_reduce", (M, H, B), t4 * (B + H)),
         9: ("fixed-order parameter-gradient sums (finalize)", None, 0.0),
         10: ("weight operands of the stack (bf16 pieces / transposes), 2 launches per direction", None, 0.0),
         11: ("cln_fwd (channel-wise LayerNorm of PReLU(.))", None, t4 * 2 * H),
         12: ("cln_bwd (input gradient + parameter-gradient partials)", None, t4 * 3 * H),
         13: ("dw_bwd_taps (depthwise weight gradient sums)", None, 0.0),
-        14: ("slab_reduce of a stack call's last weight gradient (the others are summed inside the next weight-gradient launch)", None, 0.0),
+        14: ("slab_reduce that ends a chain of weight gradients (ctn_tune wgrad_chain = 1 only)", None, 0.0),
     }
     # the forward families run as `chains` half-batch launches per block (two streams): each launch does 1 / chains of the work
     nblk = c["X"] * c["R"]

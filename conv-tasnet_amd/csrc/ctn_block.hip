@@ -375,7 +375,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = finalize(stream))) return rc;
         }
     }
-    if ((rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
+    if (chain.slab && (rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
     // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
     // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)
     if (side_stream && !(flags & 1) && (rc = ctn_stream_order(side_stream, stream))) return rc;
@@ -583,7 +583,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if (rc) return rc;
         if (!side_stream && (rc = wgrad1())) return rc;
     }
-    if ((rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
+    if (chain.slab && (rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
     // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient
     // all-reduce -- and joins later; it must then give every un-joined call a workspace of its own)
     if (side_stream && !(flags & 1) && (rc = ctn_stream_order(side_stream, stream))) return rc;

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 #include "ctn_gemm_ws.h"            // the wave-specialised h3 forward / input-gradient kernel
 
 int g_ctn_tile_override = -2;
-extern int g_ctn_cln_fr;             // csrc/ctn_tcn.hip: frames per workgroup of the channel-wise LayerNorm backward kernel
+extern int g_ctn_cln_fr;                    // csrc/ctn_tcn.hip: frames per workgroup of the channel-wise LayerNorm backward kernel
 
 // GEMM arithmetic (ctn_gemm_b3.h): 3 = "h3" (default: the composite stacks run their GEMMs on two fp16 pieces per operand under
 // tracked power-of-two scales, three f16 MFMAs -- the ctn_*_h3 entry points; every other GEMM as b6), 2 = "b6" (three bf16 pieces
@@ -663,7 +663,7 @@ static void wgrad_plan(int M, int R, int Cn, int Kp, int* tile, int* chunk, int*
 // forward / input-gradient kernels), "b3_tile_k3" (the same for the prologue + residual form), "b3_wgrad_blocks" / "wgrad_blocks"
 // (target workgroups per weight-gradient launch, split-bf16 / fp32), "pw_tile" (fp32 forward tile id 0..3, -1 = default),
 // "wgrad_chain" (below).
-static int g_ctn_wgrad_chain = 1;        // ctn_tune("wgrad_chain", 0): every weight gradient sums its own slabs (a slab_reduce launch each)
+static int g_ctn_wgrad_chain = 0;        // ctn_tune("wgrad_chain", 1): a weight gradient's slabs are summed inside the next launch of the chain (measured equal: off)
 int ctn_tune(const char* key, int value) {
     if (!key) return CTN_ERR_ARG;
     if (!strcmp(key, "pw_tile") && value >= -1 && value <= 3) g_ctn_tile_override = value;

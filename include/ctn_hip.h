@@ -89,9 +89,9 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE); "b3_ws" 0|1 (default 0): run the h3 forward /
  * input-gradient GEMMs on the wave-specialised persistent kernel (csrc/ctn_gemm_ws.h; same values, measured slower: kept as a tested
  * experiment), "b3_ws_blocks": its workgroup count; "cln_fr" 16|32: frames per workgroup of the channel-wise LayerNorm backward
- * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()); "wgrad_chain" 0|1 (default 1): inside the
- * composite stacks the split-K slabs of a weight gradient are summed by the NEXT weight-gradient launch of the stream (same
- * addition order, same bits; 0: a slab_reduce launch after every weight gradient).  Defaults are the measured best. */
+ * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()); "wgrad_chain" 0|1 (default 0): inside the
+ * composite stacks the split-K slabs of a weight gradient are summed by the NEXT weight-gradient launch of the stream instead of a
+ * slab_reduce launch of their own (same addition order, same bits; measured equal in the step).  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
  *   3 = "h3" (default): the GEMMs of the composite stacks (ctn_tcn_*) run on the ctn_*_h3 entry points below -- two fp16 pieces

@@ -95,7 +95,7 @@ def test_bucketed_backward_equals_the_single_call(norm, causal, side):
 @pytest.mark.parametrize("norm,causal", [("gLN", False), ("cLN", True)])
 def test_chained_weight_gradients_equal_the_unchained(norm, causal, side):
     """Inside the composite stacks the split-K slabs of a weight gradient are summed by the next weight-gradient launch of the
-    stream (ctn_tune("wgrad_chain", 1), the default) instead of a slab_reduce launch of their own: the same additions in the same
+    stream (ctn_tune("wgrad_chain", 1); opt-in) instead of a slab_reduce launch of their own: the same additions in the same
     order, so every gradient must be BITWISE the un-chained one's -- at widths where the split kernels run (B = 64, H = 128), an
     odd number of blocks per call, with the weight gradients on the second stream and on the main one."""
     from conv_tasnet_amd import ops
@@ -119,7 +119,7 @@ def test_chained_weight_gradients_equal_the_unchained(norm, causal, side):
         assert torch.equal(grads[0], grads[1]), "%d gradient elements differ" % int((grads[0] != grads[1]).sum())
         assert torch.equal(grads[1], grads[2])
     finally:
-        ctn.lib.call("ctn_tune", b"wgrad_chain", 1)
+        ctn.lib.call("ctn_tune", b"wgrad_chain", 0)
         ops._SIDE_ENABLED = saved_side
 
 
@@ -452,7 +452,7 @@ def test_library_probe_brackets_every_launch_group_of_the_stacks():
         assert ids.count(f) == 6 * chains, (f, ids.count(f))
     for f in (3, 4, 5, 6, 7, 8, 9):
         assert ids.count(f) == 6, (f, ids.count(f))
-    assert ids.count(14) >= 1           # chained weight gradients: one slab_reduce per stack call (the last launch's slabs)
+    assert ids.count(14) == 0           # (14: the slab_reduce that ends a chain of weight gradients, ctn_tune("wgrad_chain", 1))
     assert ctn.lib.load().ctn_probe_read(fam, us, 512) == 0         # recording ended
     m(mix.to(DEV))
     assert ctn.lib.load().ctn_probe_read(fam, us, 512) == 0         # and off
