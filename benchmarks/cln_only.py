@@ -10,6 +10,11 @@ from conv_tasnet_amd import ops  # noqa: E402
 M, H, K = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 512, 3199
 Kp = ops.padded_frames(K)
 dev = "cuda:0"
+if len(sys.argv) > 2:                   # frames per workgroup of the v4 kernels (ctn_tune "cln_fr": 16 | 32)
+    import conv_tasnet_amd as ctn
+    ctn.lib.call("ctn_tune", b"cln_fr", int(sys.argv[2]))
+    if len(sys.argv) > 3:               # 0: the general backward kernel instead of the specialised one
+        ctn.lib.call("ctn_tune", b"cln_lean", int(sys.argv[3]))
 y = torch.randn(M, H, Kp, device=dev); y[..., K:] = 0
 dout = torch.randn(M, H, Kp, device=dev); dout[..., K:] = 0
 g, b = torch.randn(1, H, 1, device=dev), torch.randn(1, H, 1, device=dev)

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 #include "ctn_gemm_ws.h"            // the wave-specialised h3 forward / input-gradient kernel
 
 int g_ctn_tile_override = -2;
+extern int g_ctn_cln_lean;
 extern int g_ctn_cln_fr;                    // csrc/ctn_tcn.hip: frames per workgroup of the channel-wise LayerNorm backward kernel
 
 // GEMM arithmetic (ctn_gemm_b3.h): 3 = "h3" (default: the composite stacks run their GEMMs on two fp16 pieces per operand under
@@ -676,6 +677,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "b3_ws") && (value == 0 || value == 1)) g_ctn_b3_ws = value;
     else if (!strcmp(key, "b3_ws_blocks") && value >= 1) g_ctn_b3_ws_blocks = value;
     else if (!strcmp(key, "wgrad_chain") && (value == 0 || value == 1)) g_ctn_wgrad_chain = value;
+    else if (!strcmp(key, "cln_lean") && (value == 0 || value == 1)) g_ctn_cln_lean = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }

@@ -847,7 +847,10 @@ __global__ __launch_bounds__(NTB) void cln_fwd_v4_kernel(const float* __restrict
 // then stores 64 KiB, and nothing on the CU overlaps those phases.  (256 threads, 16 frames) has the same channel groups, registers
 // and instruction stream per thread, but three independent workgroups fit a CU; its 64-byte row pieces pair up into whole
 // 128-byte lines with the neighbouring workgroup, which the XCD-contiguous block order keeps on the same L2.
-template <int CPT, int NTB, int FR = C4_FR>
+// LEAN: the form the composite stacks launch -- every channel group full (Ch == NG * CPT), PReLU fused, no added gradient, no ReLU
+// mask: the per-channel and per-element option tests become compile-time (1481 -> ~1000 VALU instructions per wave; the kernel spends
+// about a third of its time issuing them).  Same arithmetic, same order: bitwise the general form.
+template <int CPT, int NTB, int FR = C4_FR, bool LEAN = false>
 __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                            float* __restrict__ dY, const float* __restrict__ mean_i,
                                                            const float* __restrict__ rstd_i, int M, int Ch, int K, int Kp,
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
     const int kb = Kp / FR, nblk = M * kb;
     const int bx = FR == C4_FR ? (int)blockIdx.x : xcd_remap((int)blockIdx.x, nblk);        // FR 16: the two halves of a 128-byte line on one XCD
     const int m = bx / kb, k0 = (bx % kb) * FR + 4 * q;
-    const bool has_a = alpha_p != nullptr;
+    const bool has_a = LEAN || alpha_p != nullptr;
     const float al = has_a ? alpha_p[0] : 1.f;
     const size_t off = (size_t)m * Ch * Kp + k0;
     const float4 mu = ld4(mean_i + (size_t)m * Kp + k0), rs = ld4(rstd_i + (size_t)m * Kp + k0);
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
         const int c = g + NG * j;
         float4 y = make_float4(0.f, 0.f, 0.f, 0.f), d = y;
         float ga = 0.f;
-        if (c < Ch) {
+        if (LEAN || c < Ch) {
             y = ld4(Y + off + (size_t)c * Kp);
             d = ld4(dOut + off + (size_t)c * Kp);
             ga = gamma[c];
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
         float pg = (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w), pb = (d.x + d.y) + (d.z + d.w);
 #pragma unroll
         for (int o = 1; o < NQ; o <<= 1) { pg += __shfl_xor(pg, o, 64); pb += __shfl_xor(pb, o, 64); }
-        if (q == 0 && c < Ch) {
+        if (q == 0 && (LEAN || c < Ch)) {
             pc[(size_t)bx * Ch + c] = pg;
             pc[((size_t)nblk + bx) * Ch + c] = pb;
         }
@@ -900,17 +903,19 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
     m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
     m2.x *= inv; m2.y *= inv; m2.z *= inv; m2.w *= inv;
     float dal = 0.f, amax = 0.f;
+    const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+    const float a1[4] = {m1.x, m1.y, m1.z, m1.w}, a2[4] = {m2.x, m2.y, m2.z, m2.w};
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int c = g + NG * j;
-        if (c < Ch) {
+        if (LEAN || c < Ch) {
             const size_t o = off + (size_t)c * Kp;
             const float yy[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w}, tt[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
-            const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
-            const float a1[4] = {m1.x, m1.y, m1.z, m1.w}, a2[4] = {m2.x, m2.y, m2.z, m2.w};
             float4 ad = make_float4(0.f, 0.f, 0.f, 0.f), rf = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (add != nullptr) ad = ld4(add + o);
-            if (relu_ref != nullptr) rf = ld4(relu_ref + o);
+            if constexpr (!LEAN) {
+                if (add != nullptr) ad = ld4(add + o);
+                if (relu_ref != nullptr) rf = ld4(relu_ref + o);
+            }
             const float av[4] = {ad.x, ad.y, ad.z, ad.w}, rv[4] = {rf.x, rf.y, rf.z, rf.w};
             float r[4];
 #pragma unroll
@@ -922,8 +927,10 @@ __global__ __launch_bounds__(NTB) void cln_bwd_v4_kernel(const float* __restrict
                 if (vm[e] != 0.f) {
                     if (has_a && yy[e] < 0.f) dal += da * yy[e];
                     x = (has_a && yy[e] < 0.f) ? al * da : da;
-                    x += av[e];
-                    if (!(rv[e] > 0.f)) x = 0.f;
+                    if constexpr (!LEAN) {
+                        x += av[e];
+                        if (!(rv[e] > 0.f)) x = 0.f;
+                    }
                 }
                 r[e] = x;
             }
@@ -1238,6 +1245,7 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
 // (512 threads); ctn_tune("cln_fr", 16 | 32).  The backward partial buffers are sized and summed by this count for every kernel
 // of the family.
 int g_ctn_cln_fr = 16;
+int g_ctn_cln_lean = 1;          // ctn_tune("cln_lean", 0 | 1): the specialised backward kernel for the stacks' form
 
 static bool cln_v4_ok(int Ch, int Kp, const void* a, const void* b, const void* c) {
     return Ch <= 8 * C4_NG && Kp % C4_FR == 0 && aligned16(a) && aligned16(b) && aligned16(c);
@@ -1298,7 +1306,10 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
         const dim3 grid((unsigned)rows);
 #define CTN_CLN_BWD4(CPT_) do { if (g_ctn_cln_fr == 16) hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, 256, 16>), grid, dim3(256), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out); \
                                 else hipLaunchKernelGGL((cln_bwd_v4_kernel<CPT_, C4_NT, C4_FR>), grid, dim3(C4_NT), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out); } while (0)
-        if (Ch <= C4_NG) CTN_CLN_BWD4(1);
+        // the stacks' form (every channel group full, PReLU fused, no added gradient, no ReLU mask) has a kernel of its own
+        const bool lean = g_ctn_cln_lean && Ch == 8 * C4_NG && g_ctn_cln_fr == 16 && alpha && !add && !relu_ref;
+        if (lean) hipLaunchKernelGGL((cln_bwd_v4_kernel<8, 256, 16, true>), grid, dim3(256), 0, st, dOut, Y, dY, mean, rstd, M, Ch, K, Kp, gamma, alpha, add, relu_ref, dap, pc, amax_out);
+        else if (Ch <= C4_NG) CTN_CLN_BWD4(1);
         else if (Ch <= 2 * C4_NG) CTN_CLN_BWD4(2);
         else if (Ch <= 4 * C4_NG) CTN_CLN_BWD4(4);
         else CTN_CLN_BWD4(8);

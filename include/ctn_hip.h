@@ -89,7 +89,8 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * "pw_tile" -1|0..3: tile of the fp32-MFMA forward kernel (also CTN_PW_TILE); "b3_ws" 0|1 (default 0): run the h3 forward /
  * input-gradient GEMMs on the wave-specialised persistent kernel (csrc/ctn_gemm_ws.h; same values, measured slower: kept as a tested
  * experiment), "b3_ws_blocks": its workgroup count; "cln_fr" 16|32: frames per workgroup of the channel-wise LayerNorm backward
- * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()); "wgrad_chain" 0|1 (default 0): inside the
+ * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()); "cln_lean" 0|1 (default 1): ctn_cln_bwd at 512 channels with PReLU and without `add` /
+ * `relu_ref` runs a kernel specialised for that form (same bits, 11 % faster alone); "wgrad_chain" 0|1 (default 0): inside the
  * composite stacks the split-K slabs of a weight gradient are summed by the NEXT weight-gradient launch of the stream instead of a
  * slab_reduce launch of their own (same addition order, same bits; measured equal in the step).  Defaults are the measured best. */
 int ctn_tune(const char* key, int value);
