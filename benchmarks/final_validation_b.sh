@@ -1,4 +1,4 @@
-T=r04_final
+T=${1:-r04_final2}
 timeout -k 10 200 python -m pytest tests/test_gpu_h3.py -q -m gpu -k trajectories -s 2>&1 | grep -E "passed|failed|10 steps" | cut -c1-1200
 python bench.py --config causal --no-cpu-baseline > gpurun_out/${T}_bench_causal.json 2>> gpurun_out/${T}_bench.err
 python bench.py --config c3 --no-cpu-baseline > gpurun_out/${T}_bench_c3.json 2>> gpurun_out/${T}_bench.err
