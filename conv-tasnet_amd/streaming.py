@@ -31,9 +31,14 @@ class StreamingSeparator:
             out = s.push(chunk)         # [M, C, n*S]  (delayed by L-S samples)
         tail = s.flush()                # [M, C, L-S]
     Concatenating every `out` and `tail` reproduces ``model(full_mixture)`` on the whole signal.
+
+    ``graph=True``: a chunk is ~300 small launches issued from Python (4 ms of host time for 100 ms of audio); every chunk after
+    the first has the same shape, so from the third chunk of a given length on the whole step -- kernels, state updates, the
+    copies between them -- is replayed as ONE HIP graph (the second chunk runs eagerly and sizes the workspaces).  The state
+    lives in fixed buffers updated in place, so eager and replayed chunks can be mixed; same kernels, same order: same bits.
     """
 
-    def __init__(self, model, batch=1):
+    def __init__(self, model, batch=1, graph=False):
         if not model.causal or model.norm_type != "cLN":
             raise ValueError("streaming needs the causal cLN variant (gLN statistics span the whole utterance)")
         self.m = model
@@ -41,30 +46,59 @@ class StreamingSeparator:
         self.L, self.S = model.L, model.L // 2
         self.dev = next(model.parameters()).device
         self.soft = model.separator.softmax_mask()
+        self.use_graph = bool(graph) and self.dev.type == "cuda"
         self.reset()
 
     def reset(self):
         m, dev, M = self.m, self.dev, self.M
-        self.in_tail = torch.zeros((M, self.L - self.S), device=dev)
+        if getattr(self, "hist", None) is None:         # fixed buffers: a captured graph keeps their addresses
+            self.in_tail = torch.zeros((M, self.L - self.S), device=dev)
+            self.ola_tail = torch.zeros((M, m.C, self.L - self.S), device=dev)
+            self.hist = []
+            for rep in m.separator.network[2]:
+                for blk in rep:
+                    halo = (m.P - 1) * blk.dilation
+                    self.hist.append(torch.zeros((M, m.H, halo), device=dev))
+            self._graphs = {}            # chunk length -> (graph, static chunk, static output)
+            self._seen = {}              # chunk length -> eager steady-state chunks so far
+        else:
+            self.in_tail.zero_()
+            self.ola_tail.zero_()
+            for h in self.hist:
+                h.zero_()
         self.first = True
-        self.ola_tail = torch.zeros((M, m.C, self.L - self.S), device=dev)
-        self.hist = []
-        for rep in m.separator.network[2]:
-            for blk in rep:
-                halo = (m.P - 1) * blk.dilation
-                self.hist.append(torch.zeros((M, m.H, halo), device=dev))
 
     @torch.no_grad()
     def push(self, chunk):
-        m, S, L, M = self.m, self.S, self.L, self.M
+        S, L, M = self.S, self.L, self.M
         assert chunk.shape[0] == M and chunk.shape[1] % S == 0 and chunk.shape[1] >= L
         chunk = chunk.to(self.dev, torch.float32)
         if self.first:
-            x = chunk                                   # the very first frame starts at sample 0
             self.first = False
-        else:
-            x = torch.cat([self.in_tail, chunk], dim=1)
-        self.in_tail = x[:, x.shape[1] - (L - S):].clone()
+            return self._step(chunk, True).clone()      # the very first frame starts at sample 0
+        n = chunk.shape[1]
+        if not self.use_graph:
+            return self._step(chunk, False).clone()
+        if n not in self._graphs:
+            if self._seen.get(n, 0) < 1:                 # one eager chunk of this length first: workspaces, allocator
+                self._seen[n] = self._seen.get(n, 0) + 1
+                return self._step(chunk, False).clone()
+            static_in = chunk.clone()
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                   # records, does not run: the state is untouched until the replay
+                static_out = self._step(static_in, False)
+            self._graphs[n] = (g, static_in, static_out)
+        g, static_in, static_out = self._graphs[n]
+        static_in.copy_(chunk)
+        g.replay()
+        return static_out.clone()
+
+    def _step(self, chunk, first):
+        """One chunk through the network; carried state updated in place.  Returns a view of this step's output buffer."""
+        m, S, L, M = self.m, self.S, self.L, self.M
+        x = chunk if first else torch.cat([self.in_tail, chunk], dim=1)
+        self.in_tail.copy_(x[:, x.shape[1] - (L - S):])
         T = x.shape[1]
         K = (T - L) // S + 1
         Kp = ops.padded_frames(K)
@@ -85,7 +119,7 @@ class StreamingSeparator:
                 h, _ = ops.pw_gemm(blk.net[0].weight, y, m.H, m.B, K)
                 n1, _, _ = ops.cln_fwd(h, blk.net[2].gamma, blk.net[2].beta, blk.net[1].weight, K)
                 cat = torch.cat([self.hist[i], n1[..., :K]], dim=2)          # [M, H, halo + K]
-                self.hist[i] = cat[..., cat.shape[2] - halo:].clone()
+                self.hist[i].copy_(cat[..., cat.shape[2] - halo:])
                 Kc = halo + K
                 z, _ = ops.dw_fwd(_padded(cat, Kc), ds.net[0].weight, Kc, blk.dilation, True)
                 z = _padded(z[..., halo:Kc], K)
@@ -100,7 +134,7 @@ class StreamingSeparator:
         est = torch.empty((M, m.C, Tc), device=self.dev)
         lib.call("ctn_ola", fr.data_ptr(), est.data_ptr(), M * m.C, Tc, L, L, K, Kp, ops._stream())
         est[..., : L - S] += self.ola_tail
-        self.ola_tail = est[..., K * S:].clone()
+        self.ola_tail.copy_(est[..., K * S:])
         return est[..., : K * S]
 
     @torch.no_grad()

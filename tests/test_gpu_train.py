@@ -220,6 +220,30 @@ def test_evaluate_sisnri_matches_oracle(capsys):
     assert abs(cal_SISNR(x, x) - O.cal_sisnr_np(x, x)) < 1e-9
 
 
+def test_streaming_graph_replay_equals_eager_chunks():
+    """StreamingSeparator(graph=True): from the third chunk of a length on, the whole chunk step is one HIP-graph replay (same kernels,
+    same order, state in fixed buffers) -- every output chunk must be BITWISE the eager separator's, across a chunk of another
+    length in mid-stream, the flush and a reset()."""
+    from conv_tasnet_amd.streaming import StreamingSeparator
+    torch.manual_seed(3)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 4, 2, 2, norm_type="cLN", causal=True).to(DEV).eval()
+    S = 10
+    plan = [40, 40, 40, 40, 7, 40, 40, 7, 7, 7, 40]            # hops per chunk: 40 and 7 both reach their replay
+    T = S * sum(plan)
+    mix, _, _ = O.synth_batch(6, 2, T)
+    eager, graphed = StreamingSeparator(m, batch=2), StreamingSeparator(m, batch=2, graph=True)
+    for rnd in range(2):
+        pos = 0
+        for n in plan:
+            a, b = eager.push(mix[:, pos:pos + n * S]), graphed.push(mix[:, pos:pos + n * S])
+            assert torch.equal(a, b), (rnd, pos)
+            pos += n * S
+        assert torch.equal(eager.flush(), graphed.flush())
+        assert sorted(graphed._graphs) == [7 * S, 40 * S]
+        eager.reset()
+        graphed.reset()                                        # the captured graphs stay valid: the state buffers are the same
+
+
 def test_streaming_causal_inference_equals_full_forward():
     """chunk-by-chunk separation with carried state == one forward over the whole signal."""
     from conv_tasnet_amd.streaming import StreamingSeparator
