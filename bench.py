@@ -215,13 +215,17 @@ def family_table(probe, stack, cfg, K, steps):
     # launch groups of the composite stacks (ctn_probe_read): family id -> (name, GEMM shape (M, R, Cn) or None, tensors of
     # M*ch*K*4 bytes moved as (channels, count) pairs)
     t4 = 4.0 * M * K
+    import conv_tasnet_amd as ctn
+    cf = (not gln) and ctn.lib.load().ctn_cln_fuse() != 0       # cLN stacks: the second norm's backward rides in B1's epilogue + dw_bwd
     STACK = {
         0: ("K1 1x1 B->H (+ PReLU/gLN statistics)" if gln else "K1 1x1 B->H", (M, H, B), t4 * (B + H)),
         1: ("K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)" if gln else "K2 dw_fwd (depthwise)", None, t4 * 2 * H),
         2: ("K3 1x1 H->B (gLN prologue + residual)" if gln else "K3 1x1 H->B + residual", (M, B, H), t4 * (H + 2 * B)),
-        3: ("B1 input gradient W2^T.dout (+ gLN backward sums)" if gln else "B1 input gradient W2^T.dout", (M, H, B), t4 * (B + (2 if gln else 1) * H)),
+        3: ("B1 input gradient W2^T.dout (+ gLN backward sums)" if gln else ("B1 input gradient W2^T.dout (+ per-frame cLN backward sums)" if cf else "B1 input gradient W2^T.dout"),
+            (M, H, B), t4 * (B + (2 if (gln or cf) else 1) * H)),
         4: ("B2 weight gradient dW2 (gLN prologue) + slab_reduce" if gln else "B2 weight gradient dW2 + slab_reduce", (M, B, H), t4 * (B + H)),
-        5: ("B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)" if gln else "B3 dw_bwd (depthwise^T)", None, t4 * (4 if gln else 3) * H),
+        5: ("B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)" if gln else ("B3 dw_bwd fused (cLN2'.PReLU2'.dw^T)" if cf else "B3 dw_bwd (depthwise^T)"), None,
+            t4 * (4 if (gln or cf) else 3) * H),
         6: ("B4 gln_prelu_bwd", None, t4 * 3 * H),
         7: ("B5 input gradient W1^T.dh1 + dout", (M, B, H), t4 * (H + 2 * B)),
         8: ("B6 weight gradient dW1 + slab_reduce", (M, H, B), t4 * (B + H)),
@@ -231,6 +235,7 @@ def family_table(probe, stack, cfg, K, steps):
         12: ("cln_bwd (input gradient + parameter-gradient partials)", None, t4 * 3 * H),
         13: ("dw_bwd_taps (depthwise weight gradient sums)", None, 0.0),
         14: ("slab_reduce that ends a chain of weight gradients (ctn_tune wgrad_chain = 1 only)", None, 0.0),
+        15: ("cln_bwd_frame (per-frame constants of the fused cLN backward)", None, 0.0),
     }
     # the forward families run as `chains` half-batch launches per block (two streams): each launch does 1 / chains of the work
     nblk = c["X"] * c["R"]

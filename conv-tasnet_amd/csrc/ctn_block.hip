@@ -19,7 +19,7 @@
 // ---- measurement hook (bench.py's roofline leg): HIP events around every launch group of the composite stacks, on the stream
 // the group is launched to.  Off by default (no events, no overhead); ctn_probe_enable(1) starts a recording, ctn_probe_read
 // waits for the recorded events, returns (family id, microseconds) per launch group in issue order and ends the recording.
-enum { F_K1 = 0, F_K2, F_K3, F_B1, F_B2, F_B3, F_B4, F_B5, F_B6, F_FIN, F_PREP, F_CLN_FWD, F_CLN_BWD, F_TAPS, F_WFLUSH, F_COUNT };
+enum { F_K1 = 0, F_K2, F_K3, F_B1, F_B2, F_B3, F_B4, F_B5, F_B6, F_FIN, F_PREP, F_CLN_FWD, F_CLN_BWD, F_TAPS, F_WFLUSH, F_FRAME, F_COUNT };
 namespace {
 struct ProbeRec { int fam; hipEvent_t e0, e1; };
 std::vector<ProbeRec> g_probe;          // guarded by g_probe_mu: a second host thread that drives the library while a recording is
@@ -387,8 +387,11 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
 // ---- cLN stack (causal BASELINE config): the same host-side composite over the un-fused norm kernels ------------------
 namespace {
 struct ClnBwdWs {
-    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, amax, total, slab_bytes, pcw_slot, pcn_slot, dap_slot;
+    size_t dn2, dd, dn1, pcw, pcn, dap, slab, wp, amax, colp, fc, total, slab_bytes, pcw_slot, pcn_slot, dap_slot;
+    int ncol;
 };
+// form of the weight operand that ctn_pw_dgrad_cln gets from prepare_weights(backward): 3 h3 pieces, 2 b6 pieces, 1 the stored matrix
+inline int cln_w_form(bool h3, int twh) { return h3 ? 3 : (twh == 2 ? 2 : 1); }
 ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     ClnBwdWs w;
     size_t o = 0;
@@ -398,7 +401,7 @@ ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.dn1 = o; o += hsz;
     // parameter-gradient partials: a slot per block (two per block for the norms) -- their fixed-order sums run on the
     // weight-gradient stream while the chain is already in the next block
-    w.pcw_slot = align256((size_t)P * M * H * sizeof(float));
+    w.pcw_slot = align256((size_t)(P + 3) * M * H * sizeof(float));       // (fused second norm: taps + dgamma2, dbeta2, dalpha2 partials)
     w.pcn_slot = align256(ctn_cln_bwd_pc_floats(M, H, Kp) * sizeof(float));
     w.dap_slot = align256((size_t)ctn_cln_bwd_blocks(M, Kp) * sizeof(float));
     w.pcw = o; o += (size_t)nblocks * w.pcw_slot;
@@ -409,10 +412,17 @@ ClnBwdWs cln_bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.slab = o; o += 2 * align256(w.slab_bytes);          // two: a chained weight gradient writes one while the next launch sums the other
     w.wp = o; o += (size_t)nblocks * 2 * wslot_bytes(B, H);
     w.amax = o; o += align256((size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned));     // h3: tracked maxima of (dy, dh1) per block
+    // fused second norm (ctn_tune("cln_fuse")): per-frame column partials of the input-gradient GEMM and the per-frame constants
+    const bool h3 = use_h3(B, H);
+    w.ncol = ctn_pw_col_parts(M, H, Kp, h3 ? 3 : (pieces(H) ? 2 : 1));
+    w.colp = o; o += align256((size_t)M * w.ncol * Kp * 2 * sizeof(double));
+    w.fc = o; o += align256((size_t)M * 4 * Kp * sizeof(float));
     w.total = o;
     return w;
 }
 }  // namespace
+
+extern "C" int ctn_cln_fuse(void);       // csrc/ctn_tcn.hip
 
 extern "C" {
 
@@ -513,6 +523,9 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     float* const dn2 = (float*)(ws + w.dn2);
     float* const dd = (float*)(ws + w.dd);
     float* const dn1 = (float*)(ws + w.dn1);
+    double* const colp = (double*)(ws + w.colp);
+    float* const fc = (float*)(ws + w.fc);
+    const bool fuse = ctn_cln_fuse() != 0;
     // chained weight gradients (ctn_common.h): each launch's slabs are summed inside the next launch of the weight-gradient stream
     void* const slabs[2] = {ws + w.slab, ws + w.slab + align256(w.slab_bytes)};
     CtnWgradChain chain;
@@ -552,7 +565,11 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         float* const pcw = (float*)(ws + w.pcw + (size_t)i * w.pcw_slot);
         float* const pcn2 = (float*)(ws + w.pcn + (size_t)(2 * i) * w.pcn_slot), * const pcn1 = (float*)(ws + w.pcn + (size_t)(2 * i + 1) * w.pcn_slot);
         float* const dap2 = (float*)(ws + w.dap + (size_t)(2 * i) * w.dap_slot), * const dap1 = (float*)(ws + w.dap + (size_t)(2 * i + 1) * w.dap_slot);
-        if (h3) rc = PROBED(F_B1, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+        // fused second norm: the GEMM's epilogue also reads d and leaves the per-frame sums over channels of gamma2 dn2 and
+        // gamma2 dn2 xhat2 as column partials; the stand-alone cln_bwd pass (dn2, d -> dd: three tensor passes) is gone
+        if (fuse) rc = PROBED(F_B1, stream, ctn_pw_dgrad_cln(twh == -1 ? (const void*)p[P_W2] : (const void*)(wreg + (size_t)(2 * i) * slot), cln_w_form(h3, twh), dy, dn2,
+                              M, H, B, K, Kp, d, p[P_G2], p[P_A2], stb + 2 * ssz, stb + 3 * ssz, colp, h3 ? ady : nullptr, stream));
+        else if (h3) rc = PROBED(F_B1, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                               nullptr, nullptr, ady, nullptr, nullptr, stream));
         else rc = PROBED(F_B1, stream, ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream));
@@ -561,15 +578,24 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, ady, an, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         else rc = PROBED(F_B2, wst, ctn_pw_wgrad_chained(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         if (rc) return rc;
-        if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, nullptr, stream)))) return rc;
-        if ((rc = PROBED(F_B3, stream, ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream)))) return rc;
+        if (fuse) {
+            if ((rc = PROBED(F_FRAME, stream, ctn_cln_bwd_frame(colp, w.ncol, stb + 2 * ssz, stb + 3 * ssz, fc, M, H, Kp, stream)))) return rc;
+            if ((rc = PROBED(F_B3, stream, ctn_dw_bwd_cln(dn2, d, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, p[P_G2], p[P_A2], fc, pcw, stream)))) return rc;
+        } else {
+            if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, nullptr, stream)))) return rc;
+            if ((rc = PROBED(F_B3, stream, ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream)))) return rc;
+        }
         if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, h3 ? adh : nullptr, stream)))) return rc;
         if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
         // the three fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
         void* const fst = wst;
-        if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
-        if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
+        if (fuse) {
+            if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_cln_finalize(pcw, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
+        } else {
+            if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
+            if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
+        }
         if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst)))) return rc;
         auto wgrad1 = [&]() -> int {
             if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3_chained(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));

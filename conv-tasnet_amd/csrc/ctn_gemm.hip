@@ -429,6 +429,7 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 
 int g_ctn_tile_override = -2;
 extern int g_ctn_cln_lean;
+extern int g_ctn_cln_fuse;                  // csrc/ctn_tcn.hip: cLN stacks with the second norm's backward fused into its neighbours
 extern int g_ctn_cln_fr;                    // csrc/ctn_tcn.hip: frames per workgroup of the channel-wise LayerNorm backward kernel
 
 // GEMM arithmetic (ctn_gemm_b3.h): 3 = "h3" (default: the composite stacks run their GEMMs on two fp16 pieces per operand under
@@ -459,10 +460,11 @@ static bool b3_fwd(int R) { return arith_id() != 0 && R >= 64; }
 static bool b3_wgrad(int R, int Cn) { return arith_id() != 0 && R >= 32 && Cn >= 32; }
 
 template <typename TL>
-static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd,
+static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd,
                         hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
+    if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
+    else if (gln_bwd) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
         if (pro && residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
         else if (pro) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
@@ -532,7 +534,7 @@ extern "C" int ctn_debug_timeline(unsigned long long* dst, int n) {
 }
 #endif
 
-static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, bool gln_bwd, hipStream_t st) {
+static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd, hipStream_t st) {
     const int id = pick_tile(a.M, a.R, a.Kp);
     int tm, tn;
     tile_dims(id, &tm, &tn);
@@ -678,6 +680,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "b3_ws_blocks") && value >= 1) g_ctn_b3_ws_blocks = value;
     else if (!strcmp(key, "wgrad_chain") && (value == 0 || value == 1)) g_ctn_wgrad_chain = value;
     else if (!strcmp(key, "cln_lean") && (value == 0 || value == 1)) g_ctn_cln_lean = value;
+    else if (!strcmp(key, "cln_fuse") && (value == 0 || value == 1)) g_ctn_cln_fuse = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }
@@ -845,6 +848,40 @@ int ctn_pw_dgrad_gln_h3(const void* Wp, const float* dOut, float* dN, int M, int
     if (!ctn_ws_launch(a, false, false, false, false, true, (hipStream_t)stream))
         ctn_b3_launch_fwd(4, a, 2, false, false, false, false, true, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln_h3");
+    return CTN_OK;
+}
+
+// ---- channel-wise LayerNorm backward fused into the input-gradient GEMM (round 4): dN[m] = W^T . dOut[m] plus, per FRAME, the two
+// sums over channels that cLN backward needs (S1[k] = sum_c gamma_c dN[c,k], S2[k] = sum_c gamma_c dN[c,k] xhat[c,k]) as per-row-tile
+// column partials.  w_form: 1 = W stored fp32 [Cn, R] (arithmetic by ctn_tune("arith")), 2 = b6 pieces (ctn_split_b3_batch, k_major = 1),
+// 3 = h3 pieces (ctn_split_h3_batch; g_amax = tracked maximum of dOut).  See include/ctn_hip.h.
+static bool col_b3(int R, int w_form) { return w_form == 3 || (w_form == 2) || (w_form == 1 && b3_fwd(R)); }
+
+int ctn_pw_col_parts(int M, int R, int Kp, int w_form) {
+    int tm, tn;
+    if (col_b3(R, w_form)) ctn_b3_tile_dims(&tm, &tn);
+    else tile_dims(pick_tile(M, R, Kp), &tm, &tn);
+    return ctn_cdiv(R, tm);
+}
+
+int ctn_pw_dgrad_cln(const void* W, int w_form, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                     const float* y, const float* gamma, const float* alpha, const float* mean, const float* rstd,
+                     double* col_part, const unsigned* g_amax, void* stream) {
+    int rc = check_common("ctn_pw_dgrad_cln", (const float*)W, dOut, dN, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(w_form >= 1 && w_form <= 3, "ctn_pw_dgrad_cln: w_form must be 1 (fp32 [Cn, R]), 2 (b6 pieces) or 3 (h3 pieces)");
+    CTN_REQUIRE(y && gamma && alpha && mean && rstd && col_part, "ctn_pw_dgrad_cln: null pointer");
+    CTN_REQUIRE(aligned16(y) && aligned16(mean) && aligned16(rstd) && aligned16(col_part), "ctn_pw_dgrad_cln: y, mean, rstd, col_part must be 16-byte aligned");
+    CTN_REQUIRE(w_form != 3 || (g_amax && R >= 64), "ctn_pw_dgrad_cln: h3 pieces need the operand's maximum and R >= 64");
+    CTN_REQUIRE(w_form != 2 || b3_fwd(R), "ctn_pw_dgrad_cln: b6 pieces need a split-bf16 arithmetic and R >= 64");
+    PwArgs a{};
+    a.W = (const float*)W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.cln_mean = mean; a.cln_rstd = rstd; a.col_part = col_part;
+    a.x_amax = g_amax;
+    if (w_form == 3) ctn_b3_launch_fwd(4, a, 2, false, false, false, false, 2, (hipStream_t)stream);
+    else if (col_b3(R, w_form)) ctn_b3_launch_fwd(arith_np(), a, w_form == 2 ? 2 : 1, false, false, false, false, 2, (hipStream_t)stream);
+    else launch_fwd(a, 1, false, false, false, false, 2, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_dgrad_cln");
     return CTN_OK;
 }
 

@@ -14,7 +14,7 @@ constexpr int NT = 256;
 constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
 
 enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4, EPI_CLN_BWD = 5 };
 
 // Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
 // in 32x32 MFMA tiles.  Smaller tiles trade operand reuse (plentiful: one fp32 MFMA = 64 cycles for one
@@ -60,6 +60,10 @@ struct PwArgs {
     const float* epi_alpha; double* epi_part;      // EPI_PRELU_STATS: [M, tiles_r*tiles_c, 2]
     const float* bwd_y; const float* bwd_gamma; const float* bwd_alpha;
     const float* bwd_ms; double* bwd_part;         // EPI_GLN_BWD
+    // EPI_CLN_BWD (channel-wise LayerNorm backward, per-FRAME sums over the rows = channels): bwd_y / bwd_gamma / bwd_alpha as above,
+    // the norm's saved per-frame statistics, and the per-row-tile column partials col_part [M][tiles_r][Kp][2] =
+    // (sum_c gamma_c dN[c,k], sum_c gamma_c dN[c,k] xhat[c,k]) over the tile's rows (summed over tiles_r by ctn_cln_bwd_frame)
+    const float* cln_mean; const float* cln_rstd; double* col_part;
     // h3 arithmetic (ctn_gemm_b3.h): range information of the operands, all optional elsewhere
     const unsigned* x_amax;   // [M][CTN_AMAX_SLOTS] max |X[m]| as stored (before the prologue): scale of the B operand
     const float* pro_gbmax;   // {max |gamma|, max |beta|} of the prologue's norm
@@ -125,6 +129,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         b_mean = a.bwd_ms[2 * m];
         b_rstd = a.bwd_ms[2 * m + 1];
     }
+    if constexpr (EPI == EPI_CLN_BWD) e_alpha = a.bwd_alpha[0];
     constexpr int LST = TL::LDS_ST;
     constexpr int C4 = WN / 4;              // lanes per staged row
     constexpr int RPP = 64 / C4;            // rows per pass
@@ -135,13 +140,22 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, mat_bytes);
     __amdgpu_buffer_rsrc_t rsAux = rsOut, rsGam = rsOut;
     if constexpr (EPI == EPI_RESIDUAL) rsAux = make_rsrc(a.residual + mbase, mat_bytes);
-    if constexpr (EPI == EPI_GLN_BWD) {
+    if constexpr (EPI == EPI_GLN_BWD || EPI == EPI_CLN_BWD) {
         rsAux = make_rsrc(a.bwd_y + mbase, mat_bytes);
         rsGam = make_rsrc(a.bwd_gamma, (unsigned)a.R * 4u);
     }
     const bool ragged = c0 + TN > a.Kp;     // uniform
     const int rl0 = lane / C4, cl = (lane % C4) * 4;
     const int kcol = c0 + wn * WN + cl;
+    // EPI_CLN_BWD: this thread's four frames keep their columns through every pass: per-frame statistics once, column sums in registers
+    float4 c_mu = make_float4(0.f, 0.f, 0.f, 0.f), c_rs = c_mu;
+    float cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_CLN_BWD) {
+        if (!ragged || kcol < a.Kp) {
+            c_mu = ld4(a.cln_mean + (size_t)m * a.Kp + kcol);
+            c_rs = ld4(a.cln_rstd + (size_t)m * a.Kp + kcol);
+        }
+    }
     const int vo0 = ((r0 + wm * WM + rl0) * a.Kp + kcol) * 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -187,6 +201,17 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     s1 += (t0 + t1) + (t2 + t3);
                     s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
                 }
+                if constexpr (EPI == EPI_CLN_BWD) {
+                    // (rows >= R: gamma reads 0 through the range check and y reads 0: both sums get exact zeros)
+                    const float4 y = buf_ld4(rsAux, vo0, so);
+                    const float g = buf_ld1(rsGam, (r0 + wm * WM + rl0) * 4, (mt * 32 + p * RPP) * 4);
+                    const float t0 = g * v.x, t1 = g * v.y, t2 = g * v.z, t3 = g * v.w;
+                    cs1[0] += t0; cs1[1] += t1; cs1[2] += t2; cs1[3] += t3;
+                    cs2[0] += t0 * ((prelu_f(y.x, e_alpha) - c_mu.x) * c_rs.x);
+                    cs2[1] += t1 * ((prelu_f(y.y, e_alpha) - c_mu.y) * c_rs.y);
+                    cs2[2] += t2 * ((prelu_f(y.z, e_alpha) - c_mu.z) * c_rs.z);
+                    cs2[3] += t3 * ((prelu_f(y.w, e_alpha) - c_mu.w) * c_rs.w);
+                }
                 // The pass offset rides in the per-lane offset, not in an SGPR soffset.  hipcc (ROCm 7.2) takes a 16-byte buffer
                 // store with a REGISTER soffset to need no wait state before a VALU write of its data registers and may schedule
                 // one right behind it (40 such pairs in the round-3 listings of these epilogues, e.g. buffer_store_dwordx4 v[2:5]
@@ -201,6 +226,35 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     if constexpr (EPI == EPI_RESIDUAL) {
         // (rows >= R / columns >= Kp never reach `amax`: the loop skips them or they are exact zeros)
         if (a.out_amax != nullptr) block_amax_atomic<TL::NTH>(amax, red, a.out_amax + (size_t)m * CTN_AMAX_SLOTS, ct * a.tiles_r + rt);
+    }
+    if constexpr (EPI == EPI_CLN_BWD) {
+        // column sums of this tile's rows: the thread's rows in fp32 (8-16 terms), then fp64 over the row groups of the wave
+        // (lanes C4 apart), then over the row waves through LDS in wave order -- a fixed order: bitwise reproducible
+        double dv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dv[e] = (double)cs1[e]; dv[4 + e] = (double)cs2[e]; }
+#pragma unroll
+        for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dv[e] += __shfl_xor(dv[e], o, 64);
+        double* const cs = reinterpret_cast<double*>(smem);         // [WGM][TN][2]; the staging patches are free after the barrier
+        __syncthreads();
+        if (rl0 == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cs[((wm * TN) + wn * WN + cl + e) * 2] = dv[e];
+                cs[((wm * TN) + wn * WN + cl + e) * 2 + 1] = dv[4 + e];
+            }
+        }
+        __syncthreads();
+        if (tid < TN && c0 + tid < a.Kp) {
+            double q1 = cs[tid * 2], q2 = cs[tid * 2 + 1];
+#pragma unroll
+            for (int w = 1; w < TL::WGM; ++w) { q1 += cs[(w * TN + tid) * 2]; q2 += cs[(w * TN + tid) * 2 + 1]; }
+            double* const dst = a.col_part + (((size_t)m * a.tiles_r + rt) * a.Kp + c0 + tid) * 2;
+            dst[0] = q1;
+            dst[1] = q2;
+        }
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {
         const double d1 = block_sum<double, TL::NTH>((double)s1, red);

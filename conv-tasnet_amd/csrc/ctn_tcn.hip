@@ -167,8 +167,14 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
 //            dN1[k] = sum_j D[j]*dd[k - j*dil + padl] ;  dD[j] = sum_k dd[k]*n1[k + j*dil - padl]
 //          plus every per-channel / per-utterance sum the two norms and PReLUs need.
 //   PLAIN: dd = dZ, n1 = X as stored.
-// per-row float outputs pc[f][m][c]:  f = 0..P-1: dD ; FUSED adds P: dgamma2, P+1: dbeta2,
-//   P+2: dgamma1, P+3: dbeta1, P+4: dalpha2
+//   CLN (round 4; channel-wise LayerNorm, the causal config): dd as in FUSED but with PER-FRAME constants of the second norm --
+//          fc [M][4][Kp] = (rstd2, mean2 rstd2, rstd2 S1/H, rstd2 S2/H)[k] from ctn_cln_bwd_frame (S1, S2: the per-frame sums over
+//          channels that the input-gradient GEMM's epilogue produced) -- and n1 = X as stored (the first norm's output):
+//            xh2 = prelu(d) fc0 - fc1 ; da2 = g2 fc0 dN2 - fc2 - xh2 fc3 ; dd = da2 * prelu'(d)
+//          i.e. the whole stand-alone cLN-backward pass of the second norm (three tensor passes) rides in this kernel's dd image.
+// Template: DDM = how dd is formed (0 plain, 1 gLN, 2 cLN), XM = how the x image is formed (0 as stored, 1 gLN-1 recomputed from h1).
+// per-row float outputs pc[f][m][c]:  f = 0..P-1: dD ; (DDM, XM) = (1, 1) adds P: dgamma2, P+1: dbeta2,
+//   P+2: dgamma1, P+3: dbeta1, P+4: dalpha2 ; (2, 0) adds P: dgamma2, P+1: dbeta2, P+2: dalpha2
 // ---------------------------------------------------------------------------
 struct DwBwdArgs {
     const float* dN2; const float* Dz; const float* Y1; float* dN1; const float* D;
@@ -178,10 +184,13 @@ struct DwBwdArgs {
     const double* sums2_part; int sums2_nparts;
     float* pc;             // [F, M, H]
     double* sums1_part;    // [M, H, 2]
+    const float* fc2;      // DDM = 2: [M][4][Kp] per-frame constants of the second norm's backward
 };
 
-template <bool FUSED, int BWD_BUF, bool VEC4, int PT>
+template <int DDM, int XM, int BWD_BUF, bool VEC4, int PT>
 __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
+    static_assert((DDM == 0 && XM == 0) || (DDM == 1 && XM == 1) || (DDM == 2 && XM == 0), "supported forms");
+    constexpr bool FUSED = DDM == 1;        // (the gLN form couples both images)
     __shared__ __attribute__((aligned(16))) float bufA[ROWS][BWD_BUF];  // dd
     __shared__ __attribute__((aligned(16))) float bufB[ROWS][BWD_BUF];  // xh1 (FUSED) or x (PLAIN)
     __shared__ double red[NT / 64];
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
     const bool live = c < a.H;
     const size_t row = ((size_t)m * a.H + (live ? c : 0)) * a.Kp;
     const float* __restrict__ dn2 = a.dN2 + row;
-    const float* __restrict__ dz = FUSED ? a.Dz + row : nullptr;
+    const float* __restrict__ dz = DDM != 0 ? a.Dz + row : nullptr;
+    const float* __restrict__ fcm = DDM == 2 ? a.fc2 + (size_t)m * 4 * a.Kp : nullptr;
     const float* __restrict__ y1 = a.Y1 + row;
     float* __restrict__ dn1 = a.dN1 + row;
     float* __restrict__ LA = bufA[wave];
@@ -215,6 +225,10 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
         mean2 = a.ms2[2 * m]; rstd2 = a.ms2[2 * m + 1];
         al1 = a.a1[0]; al2 = a.a2[0];
         if (live) { g1 = a.g1[c]; b1 = a.b1[c]; g2 = a.g2[c]; }
+    }
+    if constexpr (DDM == 2) {
+        al2 = a.a2[0];
+        if (live) g2 = a.g2[c];
     }
     constexpr int NP = PT ? PT : MAXP;
     const int P_ = PT ? PT : a.P;
@@ -254,6 +268,27 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                             const bool valid = all_valid || (k + e) < a.K;
                             const float xh = fmaf(dd_[e], dd_[e] >= 0.f ? rstd2 : ar2, -mr2);    // (prelu(d)-mean2)*rstd2
                             const float da = fmaf(-xh, rc2, fmaf(rg2, vv[e], -rc1));            // rstd2*(g2*dn2 - c1 - xh*c2)
+                            if (own && valid) {
+                                dg2 += vv[e] * xh;
+                                db2 += vv[e];
+                                dal2 += dd_[e] < 0.f ? da * dd_[e] : 0.f;
+                            }
+                            vv[e] = valid ? (dd_[e] >= 0.f ? da : al2 * da) : 0.f;
+                        }
+                        v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                    if constexpr (DDM == 2) {
+                        const float4 d = ld4(dz + k);
+                        const float4 f0 = ld4(fcm + k), f1 = ld4(fcm + a.Kp + k), f2 = ld4(fcm + 2 * a.Kp + k), f3 = ld4(fcm + 3 * a.Kp + k);
+                        float vv[4] = {v.x, v.y, v.z, v.w};
+                        const float dd_[4] = {d.x, d.y, d.z, d.w};
+                        const float q0[4] = {f0.x, f0.y, f0.z, f0.w}, q1[4] = {f1.x, f1.y, f1.z, f1.w};
+                        const float q2[4] = {f2.x, f2.y, f2.z, f2.w}, q3[4] = {f3.x, f3.y, f3.z, f3.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool valid = all_valid || (k + e) < a.K;
+                            const float xh = fmaf(dd_[e], dd_[e] >= 0.f ? q0[e] : al2 * q0[e], -q1[e]);      // (prelu(d) - mean2[k]) rstd2[k]
+                            const float da = fmaf(-xh, q3[e], fmaf(q0[e] * g2, vv[e], -q2[e]));               // rstd2 (g2 dn2 - S1/H - xh S2/H)
                             if (own && valid) {
                                 dg2 += vv[e] * xh;
                                 db2 += vv[e];
@@ -401,6 +436,14 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
             const float v = wave_sum(dD[j]);
             if (live && lane == 0) a.pc[(size_t)j * MH + rc] = v;
         }
+    if constexpr (DDM == 2) {
+        const float v0 = wave_sum(dg2), v1 = wave_sum(db2), v4 = wave_sum(dal2);
+        if (live && lane == 0) {
+            a.pc[(size_t)(P_ + 0) * MH + rc] = v0;
+            a.pc[(size_t)(P_ + 1) * MH + rc] = v1;
+            a.pc[(size_t)(P_ + 2) * MH + rc] = v4;
+        }
+    }
     if constexpr (FUSED) {
         const float v0 = wave_sum(dg2), v1 = wave_sum(db2), v2 = wave_sum(dg1), v3 = wave_sum(db1), v4 = wave_sum(dal2);
         const double w1 = wave_sum((double)t1), w2 = wave_sum((double)t2);
@@ -1078,6 +1121,52 @@ __global__ __launch_bounds__(NT) void cln_bwd_finalize_kernel(const float* __res
         (f == 0 ? dgamma : dbeta)[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
 
+// Finish the per-(m,c) partials of dw_bwd<CLN>: pc [P+3, M, H] -> dD [H,P], dgamma2, dbeta2 [H] (sums over m in a fixed order), dalpha2 [1]
+// (last workgroup).
+__global__ __launch_bounds__(NT) void dw_bwd_cln_finalize_kernel(const float* __restrict__ pc, int P, int M, int H, float* __restrict__ dD,
+                                                                 float* __restrict__ dg2, float* __restrict__ db2, float* __restrict__ da2) {
+    __shared__ float red[NT / 64];
+    const size_t MH = (size_t)M * H;
+    if (blockIdx.x == gridDim.x - 1) {
+        float s = 0.f;
+        const float* src = pc + (size_t)(P + 2) * MH;
+        for (size_t i = threadIdx.x; i < MH; i += NT) s += src[i];
+        s = block_sum<float, NT>(s, red);
+        if (threadIdx.x == 0) da2[0] = s;
+        return;
+    }
+    const int o = blockIdx.x * NT + threadIdx.x;
+    if (o >= (P + 2) * H) return;
+    const int f = o / H, h = o % H;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += pc[(size_t)f * MH + (size_t)m * H + h];
+    if (f < P) dD[(size_t)h * P + f] = s;
+    else if (f == P) dg2[h] = s;
+    else db2[h] = s;
+}
+
+// Per-frame constants of a channel-wise LayerNorm's backward from the column partials of ctn_pw_dgrad_cln:
+//   S1[k] = sum_t part[m][t][k][0], S2[k] = sum_t part[m][t][k][1]  (t = row tiles, fixed order, fp64)
+//   fc[m][0..3][k] = (rstd, mean rstd, rstd S1 / Ch, rstd S2 / Ch)
+__global__ __launch_bounds__(NT) void cln_bwd_frame_kernel(const double* __restrict__ part, int nparts, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ fc, int M, int Ch, int Kp) {
+    const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+    if (i >= (long long)M * Kp) return;
+    const int m = (int)(i / Kp), k = (int)(i % Kp);
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < nparts; ++t) {
+        const double2 q = *reinterpret_cast<const double2*>(part + (((size_t)m * nparts + t) * Kp + k) * 2);
+        s1 += q.x;
+        s2 += q.y;
+    }
+    const float rs = rstd[i], mu = mean[i];
+    float* const o = fc + (size_t)m * 4 * Kp + k;
+    o[0] = rs;
+    o[(size_t)Kp] = mu * rs;
+    o[(size_t)2 * Kp] = rs * (float)(s1 / (double)Ch);
+    o[(size_t)3 * Kp] = rs * (float)(s2 / (double)Ch);
+}
+
 // pc [P, M, H] (the un-fused ctn_dw_bwd's tap partials) -> dD [H, P], summed over m in a fixed order
 __global__ __launch_bounds__(NT) void dw_bwd_taps_kernel(const float* __restrict__ pc, int P, int M, int H, float* __restrict__ dD) {
     const int o = blockIdx.x * NT + threadIdx.x;
@@ -1144,7 +1233,7 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
     return CTN_OK;
 }
 
-int ctn_dw_bwd_rows(int P, int fused) { return fused ? P + 5 : P; }
+int ctn_dw_bwd_rows(int P, int fused) { return fused == 1 ? P + 5 : (fused == 2 ? P + 3 : P); }
 
 // see include/ctn_hip.h.  pc is [F, M, H] with F = ctn_dw_bwd_rows(P, fused)
 int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, const float* D,
@@ -1163,35 +1252,40 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     const bool small = halo <= 128, medium = !small && halo <= 256;
     const int seg = (((small ? BWD_BUF_S : (medium ? BWD_BUF_M : BWD_BUF_L)) - halo - 8) / 64) * 64;
     CTN_REQUIRE(seg >= 64, "ctn_dw_bwd: receptive field (P-1)*dilation=%d too large", halo);
-    if (fused)
+    CTN_REQUIRE(fused >= 0 && fused <= 2, "ctn_dw_bwd: fused must be 0, 1 (gLN) or 2 (cLN: ctn_dw_bwd_cln)");
+    if (fused == 1)
         CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && sums1_part,
                     "ctn_dw_bwd: fused mode needs every norm argument");
+    if (fused == 2)         // (ms2 carries the per-frame constants fc [M][4][Kp])
+        CTN_REQUIRE(Dz && g2 && a2 && ms2 && aligned16(ms2), "ctn_dw_bwd_cln: null or unaligned argument");
     DwBwdArgs a{};
     a.dN2 = dN2; a.Dz = Dz; a.Y1 = Y1; a.dN1 = dN1; a.D = D;
     a.M = M; a.H = H; a.K = K; a.Kp = Kp; a.P = P; a.dil = dilation; a.padl = causal ? halo : halo / 2; a.seg = seg;
     a.g1 = g1; a.b1 = b1; a.a1 = a1; a.ms1 = ms1; a.g2 = g2; a.a2 = a2; a.ms2 = ms2;
     a.sums2_part = sums2_part; a.sums2_nparts = sums2_nparts; a.pc = pc; a.sums1_part = sums1_part;
+    if (fused == 2) { a.fc2 = ms2; a.ms2 = nullptr; }
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
     // float4 compute path whenever the tap offsets keep 16-byte alignment (dilation and left pad multiples of 4): with the
     // kernel size compiled in it also wins for the small-patch variant (44.7 vs 48.5 us at dilation 4..32)
     const bool vec4 = (a.dil % 4 == 0) && (a.padl % 4 == 0);
-#define CTN_DW_BWD_P(F_, PT_)                                                                                   \
+#define CTN_DW_BWD_P(D_, X_, PT_)                                                                                   \
     do {                                                                                                        \
-        if (small && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, true, PT_>), grid, block, 0, st, a);      \
-        else if (small) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_S, false, PT_>), grid, block, 0, st, a);        \
-        else if (medium && vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_M, true, PT_>), grid, block, 0, st, a);  \
-        else if (medium) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_M, false, PT_>), grid, block, 0, st, a);       \
-        else if (vec4) hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, true, PT_>), grid, block, 0, st, a);          \
-        else hipLaunchKernelGGL((dw_bwd_kernel<F_, BWD_BUF_L, false, PT_>), grid, block, 0, st, a);                   \
+        if (small && vec4) hipLaunchKernelGGL((dw_bwd_kernel<D_, X_, BWD_BUF_S, true, PT_>), grid, block, 0, st, a);      \
+        else if (small) hipLaunchKernelGGL((dw_bwd_kernel<D_, X_, BWD_BUF_S, false, PT_>), grid, block, 0, st, a);        \
+        else if (medium && vec4) hipLaunchKernelGGL((dw_bwd_kernel<D_, X_, BWD_BUF_M, true, PT_>), grid, block, 0, st, a);  \
+        else if (medium) hipLaunchKernelGGL((dw_bwd_kernel<D_, X_, BWD_BUF_M, false, PT_>), grid, block, 0, st, a);       \
+        else if (vec4) hipLaunchKernelGGL((dw_bwd_kernel<D_, X_, BWD_BUF_L, true, PT_>), grid, block, 0, st, a);          \
+        else hipLaunchKernelGGL((dw_bwd_kernel<D_, X_, BWD_BUF_L, false, PT_>), grid, block, 0, st, a);                   \
     } while (0)
-#define CTN_DW_BWD(F_)                  \
-    do {                                \
-        if (P == 3) CTN_DW_BWD_P(F_, 3);  \
-        else CTN_DW_BWD_P(F_, 0);         \
+#define CTN_DW_BWD(D_, X_)                  \
+    do {                                    \
+        if (P == 3) CTN_DW_BWD_P(D_, X_, 3);  \
+        else CTN_DW_BWD_P(D_, X_, 0);         \
     } while (0)
-    if (fused) CTN_DW_BWD(true);
-    else CTN_DW_BWD(false);
+    if (fused == 1) CTN_DW_BWD(1, 1);
+    else if (fused == 2) CTN_DW_BWD(2, 0);
+    else CTN_DW_BWD(0, 0);
 #undef CTN_DW_BWD_P
 #undef CTN_DW_BWD
     CTN_CHECK_LAUNCH("ctn_dw_bwd");
@@ -1208,6 +1302,34 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
     hipLaunchKernelGGL(dw_bwd_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, P, M, H, dD, dgamma2,
                        dbeta2, dgamma1, dbeta1, dalpha2, dalpha1_part, n_dalpha1, dalpha1);
     CTN_CHECK_LAUNCH("ctn_dw_bwd_finalize");
+    return CTN_OK;
+}
+
+// cLN form (round 4): see include/ctn_hip.h
+int ctn_dw_bwd_cln(const float* dN2, const float* Dz, const float* X1, float* dN1, const float* D,
+                   int M, int H, int K, int Kp, int P, int dilation, int causal,
+                   const float* g2, const float* a2, const float* fc, float* pc, void* stream) {
+    return ctn_dw_bwd(dN2, Dz, X1, dN1, D, M, H, K, Kp, P, dilation, causal, 2, nullptr, nullptr, nullptr, nullptr, g2, a2, fc,
+                      nullptr, 0, pc, nullptr, stream);
+}
+
+int ctn_dw_bwd_cln_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2, float* dalpha2,
+                            void* stream) {
+    CTN_REQUIRE(pc && dD && dgamma2 && dbeta2 && dalpha2, "ctn_dw_bwd_cln_finalize: null pointer");
+    CTN_REQUIRE(P >= 1 && P <= MAXP && M > 0 && H > 0, "ctn_dw_bwd_cln_finalize: bad sizes");
+    const unsigned nb = (unsigned)ctn_cdiv((P + 2) * H, NT) + 1;
+    hipLaunchKernelGGL(dw_bwd_cln_finalize_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, pc, P, M, H, dD, dgamma2, dbeta2, dalpha2);
+    CTN_CHECK_LAUNCH("ctn_dw_bwd_cln_finalize");
+    return CTN_OK;
+}
+
+int ctn_cln_bwd_frame(const double* col_part, int nparts, const float* mean, const float* rstd, float* fc, int M, int Ch, int Kp,
+                      void* stream) {
+    CTN_REQUIRE(col_part && mean && rstd && fc && nparts > 0 && M > 0 && Ch > 0 && Kp > 0, "ctn_cln_bwd_frame: bad arguments");
+    CTN_REQUIRE(aligned16(col_part), "ctn_cln_bwd_frame: col_part must be 16-byte aligned");
+    hipLaunchKernelGGL(cln_bwd_frame_kernel, dim3((unsigned)ctn_cdivll((long long)M * Kp, NT)), dim3(NT), 0, (hipStream_t)stream,
+                       col_part, nparts, mean, rstd, fc, M, Ch, Kp);
+    CTN_CHECK_LAUNCH("ctn_cln_bwd_frame");
     return CTN_OK;
 }
 
@@ -1245,6 +1367,9 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
 // (512 threads); ctn_tune("cln_fr", 16 | 32).  The backward partial buffers are sized and summed by this count for every kernel
 // of the family.
 int g_ctn_cln_fr = 16;
+int g_ctn_cln_fuse = 1;          // ctn_tune("cln_fuse", 0 | 1): composite cLN stacks run the second norm's backward inside the input-gradient
+                                 // GEMM's epilogue (per-frame sums) and the depthwise backward's dd image instead of as a pass of its own
+int ctn_cln_fuse(void) { return g_ctn_cln_fuse; }
 int g_ctn_cln_lean = 1;          // ctn_tune("cln_lean", 0 | 1): the specialised backward kernel for the stacks' form
 
 static bool cln_v4_ok(int Ch, int Kp, const void* a, const void* b, const void* c) {

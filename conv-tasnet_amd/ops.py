@@ -249,6 +249,57 @@ def pw_dgrad_gln(W, dOut, R, Cn, K, y, gamma, alpha, ms):
     return dn, part
 
 
+def pw_dgrad_cln(W, dOut, R, Cn, K, y, gamma, alpha, mean, rstd, g_amax=None):
+    """ctn_pw_dgrad_cln: dN = W^T . dOut (W stored [Cn, R]) + the per-frame column partials of the cLN backward sums, on the weight
+    form the composite stack uses (h3 pieces when g_amax is given, b6 pieces under the split arithmetics, else the stored matrix).
+    Returns (dN, col_part [M, nparts, Kp, 2] f64)."""
+    M, _, Kp = dOut.shape
+    if g_amax is not None:
+        Wp, form = h3_pieces(W, R, Cn, True), 3
+    elif _b3_planes_ok(R):
+        Wp, form = _b3_pieces(W, R, Cn, True), 2
+    else:
+        Wp, form = W, 1
+    dn = torch.empty((M, R, Kp), dtype=F32, device=dOut.device)
+    part = torch.empty((M, lib.ctn_pw_col_parts(M, R, Kp, form), Kp, 2), dtype=F64, device=dOut.device)
+    _chk(dOut, y, gamma, alpha, mean, rstd)
+    _chk_aux(g_amax)
+    lib.call("ctn_pw_dgrad_cln", _p(Wp), form, _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha), _p(mean), _p(rstd),
+             _p(part), _p(g_amax), _stream())
+    return dn, part
+
+
+def cln_bwd_frame(col_part, mean, rstd, Ch):
+    """ctn_cln_bwd_frame: fc [M, 4, Kp] = (rstd, mean rstd, rstd S1/Ch, rstd S2/Ch) per frame from ctn_pw_dgrad_cln's partials."""
+    M, nparts, Kp, _ = col_part.shape
+    fc = torch.empty((M, 4, Kp), dtype=F32, device=mean.device)
+    _chk(mean, rstd)
+    _chk_aux(col_part)
+    lib.call("ctn_cln_bwd_frame", _p(col_part), nparts, _p(mean), _p(rstd), _p(fc), M, Ch, Kp, _stream())
+    return fc
+
+
+def dw_bwd_cln(dn2, d, n1, D, K, dilation, causal, g2, a2, fc, sinks=None):
+    """ctn_dw_bwd_cln + ctn_dw_bwd_cln_finalize: cLN2 <- PReLU2 <- depthwise backward in one pass.
+    -> dn1, dD [H,1,P], dgamma2 [H], dbeta2 [H], dalpha2 [1]; sinks = (dD, dgamma2, dbeta2, dalpha2) destinations or None."""
+    M, H, Kp = d.shape
+    P = D.shape[-1]
+    dev = d.device
+    pc = torch.empty((P + 3, M, H), dtype=F32, device=dev)
+    dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+    _chk(dn2, d, n1, D, g2, a2, fc)
+    lib.call("ctn_dw_bwd_cln", _p(dn2), _p(d), _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), _p(g2), _p(a2), _p(fc),
+             _p(pc), _stream())
+    if sinks is None:
+        dD = torch.empty((H, 1, P), dtype=F32, device=dev)
+        dg, db, da = (torch.empty((H,), dtype=F32, device=dev), torch.empty((H,), dtype=F32, device=dev),
+                      torch.empty((1,), dtype=F32, device=dev))
+    else:
+        dD, dg, db, da = sinks
+    lib.call("ctn_dw_bwd_cln_finalize", _p(pc), P, M, H, _p(dD), _p(dg), _p(db), _p(da), _stream())
+    return dn1, dD, dg, db, da
+
+
 _ws_cache = {}
 
 # Weight-gradient GEMMs do not feed the backward chain (their results are only read by the optimiser), so in
@@ -876,9 +927,14 @@ class ClnBlock(torch.autograd.Function):
         # 21.7 ms/step at paper size (CONFIG=causal benchmarks/ab_step.py).  CTN_CLN_SIDE=0 turns it off.
         side = direct and _SIDE_ENABLED and _CLN_SIDE
         h3 = ctx.h3
+        fuse = lib.ctn_cln_fuse() != 0          # the second norm's backward inside the GEMM epilogue + the depthwise backward (the composite's rule)
+        ady = None
         if h3 is not None:
             ax, an = h3
             ady = absmax_rows(dout)
+        if fuse:
+            dn2, colp = pw_dgrad_cln(w2, dout, H, B, K, d, g2, a2, mean2, rstd2, g_amax=ady)
+        elif h3 is not None:
             dn2, _ = pw_gemm_h3(h3_pieces(w2, H, B, True), dout, H, B, K, ady)
         else:
             dn2, _ = pw_gemm(w2, dout, H, B, K, trans_w=True)
@@ -889,13 +945,18 @@ class ClnBlock(torch.autograd.Function):
             dW2 = pw_wgrad_h3(dout, n2, B, H, K, ady, an, out=sk[8] if direct else None)
         else:
             dW2 = pw_wgrad(dout, n2, B, H, K, out=sk[8] if direct else None)
-        dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K, sinks=(sk[6], sk[7], sk[5]) if direct else None)
-        pc = torch.empty((P, M, H), dtype=F32, device=dev)
-        dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
-        _chk(dd, n1)
-        lib.call("ctn_dw_bwd", _p(dd), 0, _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 0,
-                 0, 0, 0, 0, 0, 0, 0, 0, 0, _p(pc), 0, _stream())
-        dD = reduce_mid(pc, P, M, H).t().contiguous().view(H, 1, P)
+        if fuse:
+            fc = cln_bwd_frame(colp, mean2, rstd2, H)
+            dn1, dD, dg2, db2, da2 = dw_bwd_cln(dn2, d, n1, D, K, dilation, causal, g2, a2, fc,
+                                                sinks=(sk[4], sk[6], sk[7], sk[5]) if direct else None)
+        else:
+            dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K, sinks=(sk[6], sk[7], sk[5]) if direct else None)
+            pc = torch.empty((P, M, H), dtype=F32, device=dev)
+            dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
+            _chk(dd, n1)
+            lib.call("ctn_dw_bwd", _p(dd), 0, _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 0,
+                     0, 0, 0, 0, 0, 0, 0, 0, 0, _p(pc), 0, _stream())
+            dD = reduce_mid(pc, P, M, H).t().contiguous().view(H, 1, P)
         dh1, dg1, db1, da1 = cln_bwd(dn1, h1, mean1, rstd1, g1, a1, K, sinks=(sk[2], sk[3], sk[1]) if direct else None)
         adh = None if h3 is None else absmax_rows(dh1)
         if side:
@@ -911,7 +972,8 @@ class ClnBlock(torch.autograd.Function):
             else:
                 dW1 = pw_wgrad(dh1, x, H, B, K, out=sk[0] if direct else None)
         if direct:
-            sk[4].copy_(dD)
+            if not fuse:
+                sk[4].copy_(dD)
             return (dx,) + (None,) * 12
         return (dx, dW1.view(H, B, 1), da1, dg1.view(1, H, 1), db1.view(1, H, 1), dD, da2, dg2.view(1, H, 1),
                 db2.view(1, H, 1), dW2.view(B, H, 1), None, None, None)

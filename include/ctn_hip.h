@@ -92,8 +92,12 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()); "cln_lean" 0|1 (default 1): ctn_cln_bwd at 512 channels with PReLU and without `add` /
  * `relu_ref` runs a kernel specialised for that form (same bits, 11 % faster alone); "wgrad_chain" 0|1 (default 0): inside the
  * composite stacks the split-K slabs of a weight gradient are summed by the NEXT weight-gradient launch of the stream instead of a
- * slab_reduce launch of their own (same addition order, same bits; measured equal in the step).  Defaults are the measured best. */
+ * slab_reduce launch of their own (same addition order, same bits; measured equal in the step); "cln_fuse" 0|1 (default 1): the
+ * composite cLN stacks run the second norm's backward inside the input-gradient GEMM's epilogue and the depthwise backward
+ * (ctn_pw_dgrad_cln / ctn_cln_bwd_frame / ctn_dw_bwd_cln) instead of as a ctn_cln_bwd pass; ctn_cln_fuse() reads it.  Defaults are the
+ * measured best. */
 int ctn_tune(const char* key, int value);
+int ctn_cln_fuse(void);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
  *   3 = "h3" (default): the GEMMs of the composite stacks (ctn_tcn_*) run on the ctn_*_h3 entry points below -- two fp16 pieces
  *       per fp32 operand under a tracked power-of-two scale, three f16 MFMAs, fp32 accumulation; every other GEMM as b6;
@@ -200,6 +204,18 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
 /* Fixed-order finish of the UN-fused ctn_dw_bwd's tap partials: pc [P, M, H] -> dD [H, P] (the depthwise weight's layout). */
 int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* stream);
 
+/* cLN form of the backward (round 4; ChannelwiseLayerNorm, src/conv_tasnet.py:313-335, on the causal config's blocks :257-266):
+ * walks  cLN2 <- PReLU2 <- depthwise  in one pass, i.e. the second norm's whole backward rides in the depthwise kernel:
+ *   in : dN2 (grad of cLN2's output, from ctn_pw_dgrad_cln), Dz (= Z of the forward = cLN2's input), X1 (= the forward's input =
+ *        cLN1's output), gamma2 / alpha2, fc [M][4][Kp] per-frame constants from ctn_cln_bwd_frame
+ *   out: dN1 (grad of X1) and pc [P+3, M, H]: rows 0..P-1 dD taps, P: dgamma2, P+1: dbeta2, P+2: dalpha2 partials
+ *        (ctn_dw_bwd_rows(P, 2) rows), finished in fixed order by ctn_dw_bwd_cln_finalize: dD [H,P], dgamma2 / dbeta2 [H], dalpha2 [1]. */
+int ctn_dw_bwd_cln(const float* dN2, const float* Dz, const float* X1, float* dN1, const float* D,
+                   int M, int H, int K, int Kp, int P, int dilation, int causal,
+                   const float* g2, const float* a2, const float* fc, float* pc, void* stream);
+int ctn_dw_bwd_cln_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2, float* dalpha2,
+                            void* stream);
+
 /* dY = rstd*(gamma*dN - S1/n - xhat*S2/n) * prelu'(Y);  dalpha_part [M*H] = per-row sum over Y<0 of (..)*Y.
  * Backward of  gLN(prelu(Y)), src/conv_tasnet.py:224-225.  dY may alias dN.
  * amax_out != NULL: [M][CTN_AMAX_SLOTS], receives max |dY[m]| -- see the h3 section. */
@@ -256,7 +272,7 @@ size_t ctn_tcn_gln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks
 
 /* Measurement hook for the composite stacks (bench.py's roofline leg): ctn_probe_enable(1) makes every launch group issued
  * by ctn_tcn_*_fwd / _bwd on this thread's process record a HIP-event pair on the stream it is launched to;
- * ctn_probe_read waits for them, fills fam[i] (0..14: K1 K2 K3 B1 B2 B3 B4 B5 B6 finalize weight-prep cln_fwd cln_bwd taps last-slab-sums)
+ * ctn_probe_read waits for them, fills fam[i] (0..15: K1 K2 K3 B1 B2 B3 B4 B5 B6 finalize weight-prep cln_fwd cln_bwd taps last-slab-sums cln-frame-constants)
  * and us[i] (microseconds) in issue order for up to cap groups, returns the number recorded and ends the recording.
  * Off by default: no events, no overhead. */
 int ctn_probe_enable(int on);
@@ -296,6 +312,22 @@ int ctn_cln_bwd(const float* dOut, const float* Y, float* dY, const float* mean,
                 const float* add, const float* relu_ref, float* dalpha_part, float* pc, unsigned* amax_out, void* stream);
 int ctn_cln_bwd_blocks(int M, int Kp);
 size_t ctn_cln_bwd_pc_floats(int M, int Ch, int Kp);
+/* cLN backward WITHOUT a pass of its own (round 4), for a norm that sits between a 1x1 conv and the depthwise conv
+ * (src/conv_tasnet.py:257-266): the input-gradient GEMM of the 1x1 conv produces, besides dN = W^T . dOut, the two per-frame sums
+ * over channels that the norm's backward needs,
+ *     S1[k] = sum_c gamma_c dN[c,k],   S2[k] = sum_c gamma_c dN[c,k] xhat[c,k],   xhat = (prelu(y, alpha) - mean[k]) rstd[k],
+ * as column partials of its row tiles: col_part [M][ctn_pw_col_parts(M,R,Kp,w_form)][Kp][2] fp64 (fixed order inside a tile);
+ * ctn_cln_bwd_frame sums them over the row tiles and writes fc [M][4][Kp] = (rstd, mean rstd, rstd S1/Ch, rstd S2/Ch)[k], from which
+ * ctn_dw_bwd_cln forms  dy = rstd (gamma dN - S1/Ch - xhat S2/Ch) prelu'(y)  on the fly.
+ *   W / w_form: 1 = the stored fp32 [Cn, R] matrix used transposed (arithmetic by ctn_tune("arith")), 2 = b6 pieces
+ *   (ctn_split_b3_batch, k_major = 1), 3 = h3 pieces (ctn_split_h3_batch, k_major = 1; g_amax = tracked maximum of dOut, else NULL).
+ *   y: the norm's input [M,R,Kp]; mean, rstd: [M,Kp] saved by ctn_cln_fwd. */
+int ctn_pw_dgrad_cln(const void* W, int w_form, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                     const float* y, const float* gamma, const float* alpha, const float* mean, const float* rstd,
+                     double* col_part, const unsigned* g_amax, void* stream);
+int ctn_pw_col_parts(int M, int R, int Kp, int w_form);
+int ctn_cln_bwd_frame(const double* col_part, int nparts, const float* mean, const float* rstd, float* fc, int M, int Ch, int Kp,
+                      void* stream);
 /* One launch that finishes the partials above in fixed order: dgamma[Ch], dbeta[Ch] from pc, and dalpha[1] from
  * dalpha_part [ctn_cln_bwd_blocks(M,Kp)] when that is non-NULL. */
 int ctn_cln_bwd_finalize(const float* pc, const float* dalpha_part, int M, int Ch, int Kp, float* dgamma, float* dbeta,

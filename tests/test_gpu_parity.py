@@ -187,6 +187,76 @@ def test_temporal_block_fwd_bwd(norm_type, causal, dil_x, K):
         assert rel_err(p.grad, leaves[k].grad) < 1e-4, k
 
 
+def _cln_block_grads(B, H, K, M, dil, causal, fuse, seed=3):
+    """One cLN TemporalBlock (per-kernel path), forward + backward; fuse = ctn_tune("cln_fuse")."""
+    ctn.lib.call("ctn_tune", b"cln_fuse", int(fuse))
+    try:
+        blk = ctn.conv_tasnet.TemporalBlock(B, H, 3, 1, 0, dil, "cLN", causal).to(DEV)
+        gen = g(seed)
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.copy_((torch.randn(p.shape, generator=gen) * 0.3 + (0.25 if p.numel() == 1 else 0.0)).to(DEV))
+        Kp = ops.padded_frames(K)
+        x = pad(torch.randn(M, B, K, generator=gen), Kp).to(DEV).requires_grad_(True)
+        out = blk.fused(x, K)           # ops.ClnBlock
+        dout = pad(torch.randn(M, B, K, generator=gen), Kp).to(DEV)
+        out.backward(dout)
+        return [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    finally:
+        ctn.lib.call("ctn_tune", b"cln_fuse", 1)
+
+
+@pytest.mark.parametrize("B,H,K,M,dil,causal", [(16, 32, 300, 2, 2, True), (64, 128, 799, 2, 8, True), (256, 512, 1300, 2, 128, True),
+                                                 (64, 136, 257, 3, 1, False)])
+def test_fused_cln_backward_equals_the_standalone_pass(B, H, K, M, dil, causal):
+    """Round 4: the second norm's backward of a cLN block runs inside the input-gradient GEMM's epilogue (per-frame sums over
+    channels, ctn_pw_dgrad_cln), ctn_cln_bwd_frame and the depthwise backward's dd image (ctn_dw_bwd_cln) instead of as a
+    ctn_cln_bwd pass.  Same mathematics, other summation order: every gradient of the block agrees with the un-fused chain to a
+    few fp32 roundings, under every arithmetic (narrow layers: fp32-MFMA kernels; wide: pieces)."""
+    a = _cln_block_grads(B, H, K, M, dil, causal, True)
+    b = _cln_block_grads(B, H, K, M, dil, causal, False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert rel_err(u, v) < 2e-5, i
+    # pad frames of the input gradient stay exact zeros
+    assert float(a[0][..., K:].abs().max()) == 0.0
+    # and the fused chain is bitwise reproducible (fixed-order sums)
+    c = _cln_block_grads(B, H, K, M, dil, causal, True)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+
+
+def test_cln_backward_entry_points_against_fp64():
+    """ctn_pw_dgrad_cln + ctn_cln_bwd_frame against fp64 torch: dN, and fc = (rstd, mean rstd, rstd S1/Ch, rstd S2/Ch) per frame."""
+    M, R, Cn, K = 2, 192, 64, 333
+    gen = g(11)
+    Kp = ops.padded_frames(K)
+    W = torch.randn(Cn, R, generator=gen) * 0.2
+    dOut = pad(torch.randn(M, Cn, K, generator=gen), Kp)
+    y = pad(torch.randn(M, R, K, generator=gen), Kp)
+    gamma = torch.randn(R, generator=gen) + 1.0
+    beta = torch.randn(R, generator=gen)
+    alpha = torch.tensor([0.25])
+    yd, gd, ad = y.to(DEV), gamma.to(DEV), alpha.to(DEV)
+    _, mean, rstd = ops.cln_fwd(yd, gd, beta.to(DEV), ad, K)
+    h3 = ARITH["name"] == "h3"
+    amax = ops.absmax_rows(dOut.to(DEV)) if h3 else None
+    dn, colp = ops.pw_dgrad_cln(W.to(DEV), dOut.to(DEV), R, Cn, K, yd, gd, ad, mean, rstd, g_amax=amax)
+    fc = ops.cln_bwd_frame(colp, mean, rstd, R)
+    Wd, dOd, y64, g64 = W.double(), dOut.double(), y.double(), gamma.double()
+    dn_ref = torch.einsum("cr,mck->mrk", Wd, dOd)
+    p = torch.where(y64 >= 0, y64, 0.25 * y64)
+    mu = p.mean(dim=1, keepdim=True)
+    var = ((p - mu) ** 2).mean(dim=1, keepdim=True)
+    rs = 1.0 / torch.sqrt(var + 1e-8)
+    xh = (p - mu) * rs
+    t = g64[None, :, None] * dn_ref
+    S1, S2 = t.sum(dim=1), (t * xh).sum(dim=1)
+    assert rel_err(dn[..., :K], dn_ref[..., :K]) < 5e-6
+    ref = torch.stack([rs[:, 0], (mu * rs)[:, 0], rs[:, 0] * S1 / R, rs[:, 0] * S2 / R], dim=1)
+    for j in range(4):
+        assert rel_err(fc[:, j, :K], ref[:, j, :K]) < 2e-5, j
+
+
 # ----------------------------------------------------------------------------- whole model vs the reference's own outputs
 def _load_model(gd):
     N, L, B, H, P, X, R, C = [int(v) for v in gd["cfg"]]
