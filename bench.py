@@ -217,9 +217,11 @@ def family_table(probe, stack, cfg, K, steps):
     t4 = 4.0 * M * K
     import conv_tasnet_amd as ctn
     cf = (not gln) and ctn.lib.load().ctn_cln_fuse() != 0       # cLN stacks: the second norm's backward rides in B1's epilogue + dw_bwd
+    cf1 = (not gln) and ctn.lib.load().ctn_cln_fuse() >= 2      # and the first norm's forward in K1's epilogue + K2's prologue
     STACK = {
-        0: ("K1 1x1 B->H (+ PReLU/gLN statistics)" if gln else "K1 1x1 B->H", (M, H, B), t4 * (B + H)),
-        1: ("K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)" if gln else "K2 dw_fwd (depthwise)", None, t4 * 2 * H),
+        0: ("K1 1x1 B->H (+ PReLU/gLN statistics)" if gln else ("K1 1x1 B->H (+ per-frame PReLU/cLN statistics)" if cf1 else "K1 1x1 B->H"), (M, H, B), t4 * (B + H)),
+        1: ("K2 dw_fwd (gLN1+PReLU prologue, depthwise, statistics)" if gln else ("K2 dw_fwd (cLN1+PReLU prologue, depthwise)" if cf1 else "K2 dw_fwd (depthwise)"),
+            None, t4 * 2 * H),
         2: ("K3 1x1 H->B (gLN prologue + residual)" if gln else "K3 1x1 H->B + residual", (M, B, H), t4 * (H + 2 * B)),
         3: ("B1 input gradient W2^T.dout (+ gLN backward sums)" if gln else ("B1 input gradient W2^T.dout (+ per-frame cLN backward sums)" if cf else "B1 input gradient W2^T.dout"),
             (M, H, B), t4 * (B + (2 if (gln or cf) else 1) * H)),
@@ -235,7 +237,7 @@ def family_table(probe, stack, cfg, K, steps):
         12: ("cln_bwd (input gradient + parameter-gradient partials)", None, t4 * 3 * H),
         13: ("dw_bwd_taps (depthwise weight gradient sums)", None, 0.0),
         14: ("slab_reduce that ends a chain of weight gradients (ctn_tune wgrad_chain = 1 only)", None, 0.0),
-        15: ("cln_bwd_frame (per-frame constants of the fused cLN backward)", None, 0.0),
+        15: ("cln_stats_frame / cln_bwd_frame (per-frame statistics / backward constants of the fused cLN)", None, 0.0),
     }
     # the forward families run as `chains` half-batch launches per block (two streams): each launch does 1 / chains of the work
     nblk = c["X"] * c["R"]
@@ -245,7 +247,8 @@ def family_table(probe, stack, cfg, K, steps):
     for fid, us in stack:
         name, shape, nbytes = STACK[fid]
         per_block = per_fid[fid] / float(steps * nblk)
-        chains = 2.0 if (fid in (0, 1, 2, 11) and abs(per_block / (2.0 if fid == 11 else 1.0) - 2.0) < 1e-6) else 1.0
+        chains = float(round(per_fid.get(0, 0) / float(steps * nblk))) if fid in (0, 1, 2, 11) else 1.0      # forward: K1's launches per block = chains
+        chains = max(chains, 1.0)
         if chains > 1.0 and "half-batch" not in name:
             name += " [two half-batch launches per block]"
         f = fams.setdefault(name, {"bound": "mfma" if shape else "hbm", "us": [], "flops": 0.0, "bytes": 0.0, "b3": 0, "entry": "stack", "nprod": nprod})

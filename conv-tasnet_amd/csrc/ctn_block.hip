@@ -426,9 +426,12 @@ extern "C" int ctn_cln_fuse(void);       // csrc/ctn_tcn.hip
 
 extern "C" {
 
+// forward weight-operand form of ctn_pw_gemm_cln after prepare_weights(forward): 3 h3 pieces, 2 b6 pieces, 1 the [I, O] fp32 copy
+static int cln_fwd_w_form(int B, int H) { return use_h3(B, H) ? 3 : (pieces(H) ? 2 : 1); }
 size_t ctn_tcn_cln_fwd_workspace(int M, int B, int H, int Kp, int nblocks) {
-    (void)M; (void)Kp;
-    return (size_t)nblocks * 2 * wslot_bytes(B, H);      // [nblocks][w1 operand | w2 operand]
+    // [nblocks][w1 operand | w2 operand], then the column partials of the first 1x1 conv (ctn_tune("cln_fuse", 2))
+    return align256((size_t)nblocks * 2 * wslot_bytes(B, H)) +
+           align256((size_t)M * ctn_pw_col_parts(M, H, Kp, cln_fwd_w_form(B, H)) * Kp * 2 * sizeof(double));
 }
 size_t ctn_tcn_cln_bwd_workspace(int M, int B, int H, int Kp, int P, int nblocks) { return cln_bwd_ws(M, B, H, Kp, P, nblocks).total; }
 
@@ -441,7 +444,7 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
     CTN_REQUIRE(!h3 || amax, "ctn_tcn_cln_fwd: the h3 arithmetic needs the amax array");
     CTN_REQUIRE(M > 0 && B > 0 && H > 0 && K > 0 && Kp >= K && P >= 1, "ctn_tcn_cln_fwd: bad sizes");
     if (workspace_bytes < ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nblocks)) {
-        ctn_set_error("ctn_tcn_cln_fwd: workspace too small");
+        ctn_set_error("ctn_tcn_cln_fwd: workspace too small (%zu < %zu)", workspace_bytes, ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nblocks));
         return CTN_ERR_WORKSPACE;
     }
     const size_t xsz = (size_t)M * B * Kp, hsz = (size_t)M * H * Kp, ssz = (size_t)M * Kp;
@@ -451,6 +454,11 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
     for (int i = 0; i < nblocks; ++i)
         for (int j = 0; j < NPARAM; ++j) CTN_REQUIRE(params[(size_t)i * NPARAM + j], "ctn_tcn_cln_fwd: block %d parameter %d is null", i, j);
     if ((rc = prepare_weights(params, nblocks, B, H, false, wreg, slot, &tw1, &tw2, h3, nullptr, stream))) return rc;
+    // ctn_tune("cln_fuse", 2): the first norm has no pass and no stored output -- its per-frame statistics come out of K1's epilogue
+    // (column partials + ctn_cln_stats_frame) and the norm is applied in the depthwise kernel's prologue
+    const bool fuse1 = ctn_cln_fuse() >= 2;
+    const int wform = cln_fwd_w_form(B, H), ncol = ctn_pw_col_parts(M, H, Kp, wform);
+    double* const colp = (double*)((char*)workspace + align256((size_t)nblocks * 2 * wslot_bytes(B, H)));
     if (h3) {
         if (hipMemsetAsync(amax, 0, (size_t)nblocks * 2 * M * CTN_AMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
             ctn_set_error("ctn_tcn_cln_fwd: hipMemsetAsync failed");
@@ -477,7 +485,15 @@ int ctn_tcn_cln_fwd(const void* const* params, const int* dilation, int nblocks,
                 const size_t xo = (size_t)m0 * B * Kp, ho = (size_t)m0 * H * Kp, so = (size_t)m0 * Kp;
                 unsigned* const ax = h3 ? amax + ((size_t)(2 * i) * M + m0) * CTN_AMAX_SLOTS : nullptr;        // max |x_in|, max |n2| of this block
                 unsigned* const an = h3 ? amax + ((size_t)(2 * i + 1) * M + m0) * CTN_AMAX_SLOTS : nullptr;
-                if (step == 0 && h3)
+                double* const cp = colp + (size_t)m0 * ncol * Kp * 2;
+                if (step == 0 && fuse1)
+                    rc = PROBED(F_K1, sc, ctn_pw_gemm_cln(wreg + (size_t)(2 * i) * slot, wform, xin + xo, h1 + ho, Mc, H, B, K, Kp, p[P_A1], cp, ax, sc));
+                else if (step == 1 && fuse1)
+                    rc = PROBED(F_FRAME, sc, ctn_cln_stats_frame(cp, ncol, stb + so, stb + ssz + so, Mc, H, Kp, sc));
+                else if (step == 2 && fuse1)
+                    rc = PROBED(F_K2, sc, ctn_dw_fwd_cln(h1 + ho, d + ho, p[P_D], Mc, H, K, Kp, P, dilation[i], causal, stb + so, stb + ssz + so,
+                                                         p[P_G1], p[P_B1], p[P_A1], sc));
+                else if (step == 0 && h3)
                     rc = PROBED(F_K1, sc, ctn_pw_gemm_h3(wreg + (size_t)(2 * i) * slot, xin + xo, h1 + ho, Mc, H, B, K, Kp, nullptr, 0, nullptr, nullptr, nullptr,
                                                          nullptr, nullptr, nullptr, nullptr, ax, nullptr, nullptr, sc));
                 else if (step == 0)
@@ -525,7 +541,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
     float* const dn1 = (float*)(ws + w.dn1);
     double* const colp = (double*)(ws + w.colp);
     float* const fc = (float*)(ws + w.fc);
-    const bool fuse = ctn_cln_fuse() != 0;
+    const bool fuse = ctn_cln_fuse() != 0, fuse1 = ctn_cln_fuse() >= 2;      // fuse1: n1 was never stored (forward under the same setting)
     // chained weight gradients (ctn_common.h): each launch's slabs are summed inside the next launch of the weight-gradient stream
     void* const slabs[2] = {ws + w.slab, ws + w.slab + align256(w.slab_bytes)};
     CtnWgradChain chain;
@@ -580,7 +596,11 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         if (rc) return rc;
         if (fuse) {
             if ((rc = PROBED(F_FRAME, stream, ctn_cln_bwd_frame(colp, w.ncol, stb + 2 * ssz, stb + 3 * ssz, fc, M, H, Kp, stream)))) return rc;
-            if ((rc = PROBED(F_B3, stream, ctn_dw_bwd_cln(dn2, d, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, p[P_G2], p[P_A2], fc, pcw, stream)))) return rc;
+            if (fuse1) rc = PROBED(F_B3, stream, ctn_dw_bwd_cln(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, p[P_G2], p[P_A2], fc,
+                                                                p[P_G1], p[P_B1], p[P_A1], stb, stb + ssz, pcw, stream));
+            else rc = PROBED(F_B3, stream, ctn_dw_bwd_cln(dn2, d, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, p[P_G2], p[P_A2], fc,
+                                                          nullptr, nullptr, nullptr, nullptr, nullptr, pcw, stream));
+            if (rc) return rc;
         } else {
             if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn2, d, dd, stb + 2 * ssz, stb + 3 * ssz, M, H, K, Kp, p[P_G2], p[P_A2], nullptr, nullptr, dap2, pcn2, nullptr, stream)))) return rc;
             if ((rc = PROBED(F_B3, stream, ctn_dw_bwd(dd, nullptr, n1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 0, nullptr, nullptr, nullptr, nullptr,

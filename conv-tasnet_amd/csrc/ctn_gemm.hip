@@ -460,7 +460,7 @@ static bool b3_fwd(int R) { return arith_id() != 0 && R >= 64; }
 static bool b3_wgrad(int R, int Cn) { return arith_id() != 0 && R >= 32 && Cn >= 32; }
 
 template <typename TL>
-static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd,
+static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd,
                         hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
@@ -468,13 +468,15 @@ static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, b
     else if (trans_w) {
         if (pro && residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
         else if (pro) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+        else if (stats == 2) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_CLN_STATS>), grid, block, 0, st, a);
         else if (stats) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
         else if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
     } else if (pro) {
         if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    } else if (stats) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    } else if (stats == 2) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_CLN_STATS>), grid, block, 0, st, a);
+    else if (stats) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
     else if (residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (relu) hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pw_gemm_kernel<TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
@@ -534,7 +536,7 @@ extern "C" int ctn_debug_timeline(unsigned long long* dst, int n) {
 }
 #endif
 
-static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd, hipStream_t st) {
+static void launch_fwd(PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {
     const int id = pick_tile(a.M, a.R, a.Kp);
     int tm, tn;
     tile_dims(id, &tm, &tn);
@@ -680,7 +682,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "b3_ws_blocks") && value >= 1) g_ctn_b3_ws_blocks = value;
     else if (!strcmp(key, "wgrad_chain") && (value == 0 || value == 1)) g_ctn_wgrad_chain = value;
     else if (!strcmp(key, "cln_lean") && (value == 0 || value == 1)) g_ctn_cln_lean = value;
-    else if (!strcmp(key, "cln_fuse") && (value == 0 || value == 1)) g_ctn_cln_fuse = value;
+    else if (!strcmp(key, "cln_fuse") && value >= 0 && value <= 2) g_ctn_cln_fuse = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }
@@ -855,7 +857,7 @@ int ctn_pw_dgrad_gln_h3(const void* Wp, const float* dOut, float* dN, int M, int
 // sums over channels that cLN backward needs (S1[k] = sum_c gamma_c dN[c,k], S2[k] = sum_c gamma_c dN[c,k] xhat[c,k]) as per-row-tile
 // column partials.  w_form: 1 = W stored fp32 [Cn, R] (arithmetic by ctn_tune("arith")), 2 = b6 pieces (ctn_split_b3_batch, k_major = 1),
 // 3 = h3 pieces (ctn_split_h3_batch; g_amax = tracked maximum of dOut).  See include/ctn_hip.h.
-static bool col_b3(int R, int w_form) { return w_form == 3 || (w_form == 2) || (w_form == 1 && b3_fwd(R)); }
+static bool col_b3(int R, int w_form) { return w_form == 3 || (w_form == 2) || (w_form <= 1 && b3_fwd(R)); }
 
 int ctn_pw_col_parts(int M, int R, int Kp, int w_form) {
     int tm, tn;
@@ -882,6 +884,28 @@ int ctn_pw_dgrad_cln(const void* W, int w_form, const float* dOut, float* dN, in
     else if (col_b3(R, w_form)) ctn_b3_launch_fwd(arith_np(), a, w_form == 2 ? 2 : 1, false, false, false, false, 2, (hipStream_t)stream);
     else launch_fwd(a, 1, false, false, false, false, 2, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_dgrad_cln");
+    return CTN_OK;
+}
+
+// Forward 1x1 conv whose output feeds PReLU + channel-wise LayerNorm: Out[m] = op(W) . X[m], and per FRAME the sums over channels of
+// p = prelu(Out, alpha) and p^2 as per-row-tile column partials (layout of ctn_pw_dgrad_cln) -- the norm's statistics come out of
+// the producing GEMM instead of a pass over its output.  w_form: 0 = W stored fp32 [R, Cn], 1 = stored [Cn, R] (used transposed),
+// 2 = b6 pieces, 3 = h3 pieces (x_amax = tracked maximum of X).
+int ctn_pw_gemm_cln(const void* W, int w_form, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
+                    const float* alpha, double* col_part, const unsigned* x_amax, void* stream) {
+    int rc = check_common("ctn_pw_gemm_cln", (const float*)W, X, Out, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(w_form >= 0 && w_form <= 3, "ctn_pw_gemm_cln: w_form must be 0 (fp32 [R, Cn]), 1 (fp32 [Cn, R]), 2 (b6 pieces) or 3 (h3 pieces)");
+    CTN_REQUIRE(alpha && col_part && aligned16(col_part), "ctn_pw_gemm_cln: null or unaligned pointer");
+    CTN_REQUIRE(w_form != 3 || (x_amax && R >= 64), "ctn_pw_gemm_cln: h3 pieces need the operand's maximum and R >= 64");
+    CTN_REQUIRE(w_form != 2 || b3_fwd(R), "ctn_pw_gemm_cln: b6 pieces need a split-bf16 arithmetic and R >= 64");
+    PwArgs a{};
+    a.W = (const float*)W; a.X = X; a.Out = Out; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.epi_alpha = alpha; a.col_part = col_part; a.x_amax = x_amax;
+    if (w_form == 3) ctn_b3_launch_fwd(4, a, 2, false, false, 2, false, 0, (hipStream_t)stream);
+    else if (col_b3(R, w_form)) ctn_b3_launch_fwd(arith_np(), a, w_form, false, false, 2, false, 0, (hipStream_t)stream);
+    else launch_fwd(a, w_form, false, false, 2, false, 0, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_gemm_cln");
     return CTN_OK;
 }
 

@@ -920,12 +920,13 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
 }
 
 template <int AR, typename TL>
-void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool relu, int gln_bwd, hipStream_t st) {      // gln_bwd: 1 = EPI_GLN_BWD, 2 = EPI_CLN_BWD
+void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {      // gln_bwd: 1 = EPI_GLN_BWD, 2 = EPI_CLN_BWD; stats: 1 = EPI_PRELU_STATS, 2 = EPI_CLN_STATS
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
     else if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+    else if (stats == 2) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_CLN_STATS>), grid, block, 0, st, a);
     else if (stats) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
     else if (residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (relu) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
@@ -933,20 +934,22 @@ void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, bool stats, bool 
 }
 
 template <int AR, typename TL>
-void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd, hipStream_t st) {
+void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
     if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
     else if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
         if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
         else if (pro) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
+        else if (stats == 2) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_CLN_STATS>), grid, block, 0, st, a);
         else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
         else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
     } else if (pro) {
         if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
-    } else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
+    } else if (stats == 2) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_CLN_STATS>), grid, block, 0, st, a);
+    else if (stats) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_PRELU_STATS>), grid, block, 0, st, a);
     else if (residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (relu) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_RELU>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 0, PRO_NONE, EPI_NONE>), grid, block, 0, st, a);
@@ -969,13 +972,13 @@ static void ctn_b3_tile_dims(int* tm, int* tn) {    // the tile of every form th
     *tn = d[g_ctn_b3_tile][1];
 }
 // tile id of one launch: forms without a statistics epilogue may pick their own
-static int ctn_b3_pick_tile(const PwArgs& a, int trans_w, bool pro, bool residual, bool stats, int gln_bwd) {
+static int ctn_b3_pick_tile(const PwArgs& a, int trans_w, bool pro, bool residual, int stats, int gln_bwd) {
     if (trans_w == 2 && residual && !stats && !gln_bwd && a.R <= 256 && a.R > 128) return g_ctn_b3_tile_k3;      // K3 and B5
     return g_ctn_b3_tile;
 }
 
 template <int AR>
-static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd, hipStream_t st) {
+static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {
     if (trans_w == 2) {             // a.W = fragment-ordered pieces (ctn_split_b3_batch)
         switch (tile) {
             case 1: launch_b3p_tile<AR, Tile<128, 64, 4, 1>>(a, pro, residual, stats, relu, gln_bwd, st); break;
@@ -994,7 +997,7 @@ static void ctn_b3_launch_fwd_np(int tile, PwArgs& a, int trans_w, bool pro, boo
     }
 }
 
-static void ctn_b3_launch_fwd(int ar, PwArgs& a, int trans_w, bool pro, bool residual, bool stats, bool relu, int gln_bwd, hipStream_t st) {
+static void ctn_b3_launch_fwd(int ar, PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {
     static const int d[4][2] = {{128, 128}, {128, 64}, {256, 64}, {256, 64}};
     const int tile = ctn_b3_pick_tile(a, trans_w, pro, residual, stats, gln_bwd);
     a.tiles_r = ctn_cdiv(a.R, d[tile][0]);

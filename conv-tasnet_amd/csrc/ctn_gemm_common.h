@@ -14,7 +14,7 @@ constexpr int NT = 256;
 constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
 
 enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4, EPI_CLN_BWD = 5 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4, EPI_CLN_BWD = 5, EPI_CLN_STATS = 6 };
 
 // Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
 // in 32x32 MFMA tiles.  Smaller tiles trade operand reuse (plentiful: one fp32 MFMA = 64 cycles for one
@@ -64,6 +64,8 @@ struct PwArgs {
     // the norm's saved per-frame statistics, and the per-row-tile column partials col_part [M][tiles_r][Kp][2] =
     // (sum_c gamma_c dN[c,k], sum_c gamma_c dN[c,k] xhat[c,k]) over the tile's rows (summed over tiles_r by ctn_cln_bwd_frame)
     const float* cln_mean; const float* cln_rstd; double* col_part;
+    // EPI_CLN_STATS (channel-wise LayerNorm forward statistics from the producing GEMM): epi_alpha, and col_part receives
+    // (sum_c p, sum_c p^2), p = prelu(Out[c,k], alpha), over the tile's rows (ctn_cln_stats_frame turns them into mean / rstd)
     // h3 arithmetic (ctn_gemm_b3.h): range information of the operands, all optional elsewhere
     const unsigned* x_amax;   // [M][CTN_AMAX_SLOTS] max |X[m]| as stored (before the prologue): scale of the B operand
     const float* pro_gbmax;   // {max |gamma|, max |beta|} of the prologue's norm
@@ -130,6 +132,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         b_rstd = a.bwd_ms[2 * m + 1];
     }
     if constexpr (EPI == EPI_CLN_BWD) e_alpha = a.bwd_alpha[0];
+    if constexpr (EPI == EPI_CLN_STATS) e_alpha = a.epi_alpha[0];
     constexpr int LST = TL::LDS_ST;
     constexpr int C4 = WN / 4;              // lanes per staged row
     constexpr int RPP = 64 / C4;            // rows per pass
@@ -212,6 +215,14 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     cs2[2] += t2 * ((prelu_f(y.z, e_alpha) - c_mu.z) * c_rs.z);
                     cs2[3] += t3 * ((prelu_f(y.w, e_alpha) - c_mu.w) * c_rs.w);
                 }
+                if constexpr (EPI == EPI_CLN_STATS) {
+                    if (r0 + wm * WM + mt * 32 + rl < a.R) {        // (rows >= R of an overhanging tile: see EPI_PRELU_STATS)
+                        const float p0 = prelu_f(v.x, e_alpha), p1 = prelu_f(v.y, e_alpha);
+                        const float p2 = prelu_f(v.z, e_alpha), p3 = prelu_f(v.w, e_alpha);
+                        cs1[0] += p0; cs1[1] += p1; cs1[2] += p2; cs1[3] += p3;
+                        cs2[0] += p0 * p0; cs2[1] += p1 * p1; cs2[2] += p2 * p2; cs2[3] += p3 * p3;
+                    }
+                }
                 // The pass offset rides in the per-lane offset, not in an SGPR soffset.  hipcc (ROCm 7.2) takes a 16-byte buffer
                 // store with a REGISTER soffset to need no wait state before a VALU write of its data registers and may schedule
                 // one right behind it (40 such pairs in the round-3 listings of these epilogues, e.g. buffer_store_dwordx4 v[2:5]
@@ -227,7 +238,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
         // (rows >= R / columns >= Kp never reach `amax`: the loop skips them or they are exact zeros)
         if (a.out_amax != nullptr) block_amax_atomic<TL::NTH>(amax, red, a.out_amax + (size_t)m * CTN_AMAX_SLOTS, ct * a.tiles_r + rt);
     }
-    if constexpr (EPI == EPI_CLN_BWD) {
+    if constexpr (EPI == EPI_CLN_BWD || EPI == EPI_CLN_STATS) {
         // column sums of this tile's rows: the thread's rows in fp32 (8-16 terms), then fp64 over the row groups of the wave
         // (lanes C4 apart), then over the row waves through LDS in wave order -- a fixed order: bitwise reproducible
         double dv[8];

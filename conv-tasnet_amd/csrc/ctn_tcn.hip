@@ -38,9 +38,11 @@ struct DwFwdArgs {
     const float* pro_gamma; const float* pro_beta; const float* pro_alpha; float* pro_ms_out;
     const float* epi_alpha; double* epi_part;   // [M, H, 2]
     unsigned* amax_out;                         // EPI: [M][CTN_AMAX_SLOTS] max |Z[m]| (h3 arithmetic of the GEMM that reads Z), optional
+    const float* cln_mean; const float* cln_rstd;   // PRO = 2: [M][Kp] per-frame statistics of the channel-wise LayerNorm
 };
 
-template <bool PRO, bool EPI, int FWD_BUF, bool VEC4, int PT>      // PT: compile-time kernel size (3) or 0 = a.P at run time
+// PRO: 0 n = y, 1 n = gLN(prelu(y)) (per-utterance statistics), 2 n = cLN(prelu(y)) (per-frame statistics, round 4)
+template <int PRO, bool EPI, int FWD_BUF, bool VEC4, int PT>      // PT: compile-time kernel size (3) or 0 = a.P at run time
 __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float buf[ROWS][FWD_BUF];
     __shared__ double red[NT / 64];
@@ -55,7 +57,13 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
     float* __restrict__ L = buf[wave];
 
     float mean = 0.f, rstd = 1.f, alpha = 0.f, g = 1.f, b = 0.f;
-    if constexpr (PRO) {
+    const float* __restrict__ cmu = PRO == 2 ? a.cln_mean + (size_t)m * a.Kp : nullptr;
+    const float* __restrict__ crs = PRO == 2 ? a.cln_rstd + (size_t)m * a.Kp : nullptr;
+    if constexpr (PRO == 2) {
+        alpha = a.pro_alpha[0];
+        if (live) { g = a.pro_gamma[c]; b = a.pro_beta[c]; }
+    }
+    if constexpr (PRO == 1) {
         finalize_stats<NT>(a.pro_part + (size_t)m * a.pro_nparts * 2, a.pro_nparts, (double)a.H * (double)a.K, red,
                            mean, rstd);
         alpha = a.pro_alpha[0];
@@ -85,7 +93,14 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live && k >= 0 && k < a.Kp) {
                 v = ld4(y + k);
-                if constexpr (PRO) {       // gamma*((prelu(x)-mean)*rstd)+beta as one select + one FMA per element
+                if constexpr (PRO == 2) {  // gamma ((prelu(x) - mean[k]) rstd[k]) + beta: the order of cln_fwd_v4_kernel
+                    const float4 mu = ld4(cmu + k), rs = ld4(crs + k);
+                    v.x = k + 0 < a.K ? g * ((prelu_f(v.x, alpha) - mu.x) * rs.x) + b : 0.f;
+                    v.y = k + 1 < a.K ? g * ((prelu_f(v.y, alpha) - mu.y) * rs.y) + b : 0.f;
+                    v.z = k + 2 < a.K ? g * ((prelu_f(v.z, alpha) - mu.z) * rs.z) + b : 0.f;
+                    v.w = k + 3 < a.K ? g * ((prelu_f(v.w, alpha) - mu.w) * rs.w) + b : 0.f;
+                }
+                if constexpr (PRO == 1) {  // gamma*((prelu(x)-mean)*rstd)+beta as one select + one FMA per element
                     v.x = fmaf(v.x, v.x >= 0.f ? gs : gn, cc);
                     v.y = fmaf(v.y, v.y >= 0.f ? gs : gn, cc);
                     v.z = fmaf(v.z, v.z >= 0.f ? gs : gn, cc);
@@ -172,7 +187,8 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
 //          channels that the input-gradient GEMM's epilogue produced) -- and n1 = X as stored (the first norm's output):
 //            xh2 = prelu(d) fc0 - fc1 ; da2 = g2 fc0 dN2 - fc2 - xh2 fc3 ; dd = da2 * prelu'(d)
 //          i.e. the whole stand-alone cLN-backward pass of the second norm (three tensor passes) rides in this kernel's dd image.
-// Template: DDM = how dd is formed (0 plain, 1 gLN, 2 cLN), XM = how the x image is formed (0 as stored, 1 gLN-1 recomputed from h1).
+// Template: DDM = how dd is formed (0 plain, 1 gLN, 2 cLN), XM = how the x image is formed (0 as stored, 1 gLN-1 recomputed from h1,
+// 2 cLN-1 recomputed from h1 with its per-frame statistics: the first norm's output is never stored).
 // per-row float outputs pc[f][m][c]:  f = 0..P-1: dD ; (DDM, XM) = (1, 1) adds P: dgamma2, P+1: dbeta2,
 //   P+2: dgamma1, P+3: dbeta1, P+4: dalpha2 ; (2, 0) adds P: dgamma2, P+1: dbeta2, P+2: dalpha2
 // ---------------------------------------------------------------------------
@@ -185,12 +201,14 @@ struct DwBwdArgs {
     float* pc;             // [F, M, H]
     double* sums1_part;    // [M, H, 2]
     const float* fc2;      // DDM = 2: [M][4][Kp] per-frame constants of the second norm's backward
+    const float* mean1f; const float* rstd1f;      // XM = 2: [M][Kp] per-frame statistics of the first (channel-wise) norm
 };
 
 template <int DDM, int XM, int BWD_BUF, bool VEC4, int PT>
 __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
-    static_assert((DDM == 0 && XM == 0) || (DDM == 1 && XM == 1) || (DDM == 2 && XM == 0), "supported forms");
+    static_assert((DDM == 0 && XM == 0) || (DDM == 1 && XM == 1) || (DDM == 2 && (XM == 0 || XM == 2)), "supported forms");
     constexpr bool FUSED = DDM == 1;        // (the gLN form couples both images)
+    constexpr bool XHAT = XM != 0;          // the x image holds xhat1: gamma1 / beta1 are applied where it is read
     __shared__ __attribute__((aligned(16))) float bufA[ROWS][BWD_BUF];  // dd
     __shared__ __attribute__((aligned(16))) float bufB[ROWS][BWD_BUF];  // xh1 (FUSED) or x (PLAIN)
     __shared__ double red[NT / 64];
@@ -229,6 +247,12 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
     if constexpr (DDM == 2) {
         al2 = a.a2[0];
         if (live) g2 = a.g2[c];
+    }
+    const float* __restrict__ mu1f = XM == 2 ? a.mean1f + (size_t)m * a.Kp : nullptr;
+    const float* __restrict__ rs1f = XM == 2 ? a.rstd1f + (size_t)m * a.Kp : nullptr;
+    if constexpr (XM == 2) {
+        al1 = a.a1[0];
+        if (live) { g1 = a.g1[c]; b1 = a.b1[c]; }
     }
     constexpr int NP = PT ? PT : MAXP;
     const int P_ = PT ? PT : a.P;
@@ -313,6 +337,13 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live && k >= 0 && k < a.Kp) {
                     v = ld4(y1 + k);
+                    if constexpr (XM == 2) {
+                        const float4 mu = ld4(mu1f + k), rs = ld4(rs1f + k);
+                        v.x = (prelu_f(v.x, al1) - mu.x) * rs.x;
+                        v.y = (prelu_f(v.y, al1) - mu.y) * rs.y;
+                        v.z = (prelu_f(v.z, al1) - mu.z) * rs.z;
+                        v.w = (prelu_f(v.w, al1) - mu.w) * rs.w;
+                    }
                     if constexpr (FUSED) {
                         v.x = fmaf(v.x, v.x >= 0.f ? rstd1 : ar1, -mr1);
                         v.y = fmaf(v.y, v.y >= 0.f ? rstd1 : ar1, -mr1);
@@ -344,7 +375,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                         float xv[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if constexpr (FUSED) {
+                            if constexpr (XHAT) {
                                 const int kk = k + e - a.padl + j * a.dil;
                                 xv[e] = (kk >= 0 && kk < a.K) ? g1 * xv[e] + b1 : 0.f;
                             }
@@ -381,7 +412,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                     if (PT || j < a.P) {
                         acc += taps[j] * LA[ia - j * a.dil];
                         float xv = LB[ib + j * a.dil];
-                        if constexpr (FUSED) xv = g1 * xv + b1;
+                        if constexpr (XHAT) xv = g1 * xv + b1;
                         dD[j] += LA[k - baseA] * xv;
                     }
                 if constexpr (FUSED) {
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 if (PT || j < a.P) {
                     const int kk = k - a.padl + j * a.dil;
                     float xv = LB[ib + j * a.dil];
-                    if constexpr (FUSED) xv = (kk >= 0 && kk < a.K) ? g1 * xv + b1 : 0.f;
+                    if constexpr (XHAT) xv = (kk >= 0 && kk < a.K) ? g1 * xv + b1 : 0.f;
                     dD[j] += ddk * xv;
                 }
             if constexpr (FUSED) {
@@ -1145,6 +1176,26 @@ __global__ __launch_bounds__(NT) void dw_bwd_cln_finalize_kernel(const float* __
     else db2[h] = s;
 }
 
+// Per-frame statistics of a channel-wise LayerNorm from the column partials of ctn_pw_gemm_cln: (sum p, sum p^2) over the row tiles
+// in fixed order (fp64) -> mean, rstd = 1 / sqrt(E[p^2] - mean^2 + eps) (fp64 until the last step; biased variance).
+__global__ __launch_bounds__(NT) void cln_stats_frame_kernel(const double* __restrict__ part, int nparts, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int M, int Ch, int Kp) {
+    const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+    if (i >= (long long)M * Kp) return;
+    const int m = (int)(i / Kp), k = (int)(i % Kp);
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < nparts; ++t) {
+        const double2 q = *reinterpret_cast<const double2*>(part + (((size_t)m * nparts + t) * Kp + k) * 2);
+        s1 += q.x;
+        s2 += q.y;
+    }
+    const double mu = s1 / (double)Ch;
+    double var = s2 / (double)Ch - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)CTN_EPS));
+}
+
 // Per-frame constants of a channel-wise LayerNorm's backward from the column partials of ctn_pw_dgrad_cln:
 //   S1[k] = sum_t part[m][t][k][0], S2[k] = sum_t part[m][t][k][1]  (t = row tiles, fixed order, fp64)
 //   fc[m][0..3][k] = (rstd, mean rstd, rstd S1 / Ch, rstd S2 / Ch)
@@ -1182,6 +1233,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 }  // namespace
 
 extern "C" int ctn_absmax_rows(const float* x, int M, long long n, unsigned* amax, void* stream);      // ctn_gemm.hip
+static int dw_fwd_launch(const DwFwdArgs& a, int pro, bool epi, bool small, void* stream);
 
 extern "C" {
 
@@ -1207,6 +1259,33 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
     a.pro_part = pro_part; a.pro_nparts = pro_nparts; a.pro_gamma = pro_gamma; a.pro_beta = pro_beta;
     a.pro_alpha = pro_alpha; a.pro_ms_out = pro_ms_out; a.epi_alpha = epi_alpha; a.epi_part = epi_part;
     a.amax_out = amax_out;
+    return dw_fwd_launch(a, pro_part ? 1 : 0, epi_part != nullptr, halo <= 192, stream);
+}
+
+// channel-wise LayerNorm form (round 4): n = gamma ((prelu(Y, alpha) - mean[k]) rstd[k]) + beta with the per-frame statistics that
+// ctn_cln_stats_frame made of the producing GEMM's column partials; no separate norm pass, the norm's output is never stored
+int ctn_dw_fwd_cln(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, const float* alpha, void* stream) {
+    CTN_REQUIRE(Y && Z && D && mean && rstd && gamma && beta && alpha, "ctn_dw_fwd_cln: null pointer");
+    CTN_REQUIRE(M > 0 && H > 0 && K > 0 && Kp >= K && Kp % 4 == 0, "ctn_dw_fwd_cln: bad sizes");
+    CTN_REQUIRE(P >= 1 && P <= MAXP && dilation >= 1, "ctn_dw_fwd_cln: kernel size %d unsupported (max %d)", P, MAXP);
+    CTN_REQUIRE(aligned16(Y) && aligned16(Z) && aligned16(mean) && aligned16(rstd), "ctn_dw_fwd_cln: pointers must be 16-byte aligned");
+    const int halo = (P - 1) * dilation;
+    CTN_REQUIRE(causal || halo % 2 == 0, "ctn_dw_fwd_cln: non-causal 'same' padding needs (P-1)*dilation even");
+    const bool small = halo <= 192;
+    const int seg = (((small ? FWD_BUF_S : FWD_BUF_L) - halo - 8) / 64) * 64;
+    CTN_REQUIRE(seg >= 64, "ctn_dw_fwd_cln: receptive field (P-1)*dilation=%d too large", halo);
+    DwFwdArgs a{};
+    a.Y = Y; a.Z = Z; a.D = D; a.M = M; a.H = H; a.K = K; a.Kp = Kp; a.P = P; a.dil = dilation;
+    a.padl = causal ? halo : halo / 2; a.seg = seg;
+    a.pro_gamma = gamma; a.pro_beta = beta; a.pro_alpha = alpha; a.cln_mean = mean; a.cln_rstd = rstd;
+    return dw_fwd_launch(a, 2, false, small, stream);
+}
+
+}  // extern "C"
+
+static int dw_fwd_launch(const DwFwdArgs& a, int pro, bool epi, bool small, void* stream) {
+    const int M = a.M, H = a.H, P = a.P;
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
     const bool vec4 = (a.dil % 4 == 0) && (a.padl % 4 == 0);
@@ -1223,15 +1302,18 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
         if (P == 3) CTN_DW_FWD_P(P_, E_, 3);  \
         else CTN_DW_FWD_P(P_, E_, 0);         \
     } while (0)
-    if (pro_part && epi_part) CTN_DW_FWD(true, true);
-    else if (pro_part) CTN_DW_FWD(true, false);
-    else if (epi_part) CTN_DW_FWD(false, true);
-    else CTN_DW_FWD(false, false);
+    if (pro == 2) CTN_DW_FWD(2, false);
+    else if (pro && epi) CTN_DW_FWD(1, true);
+    else if (pro) CTN_DW_FWD(1, false);
+    else if (epi) CTN_DW_FWD(0, true);
+    else CTN_DW_FWD(0, false);
 #undef CTN_DW_FWD_P
 #undef CTN_DW_FWD
     CTN_CHECK_LAUNCH("ctn_dw_fwd");
     return CTN_OK;
 }
+
+extern "C" {
 
 int ctn_dw_bwd_rows(int P, int fused) { return fused == 1 ? P + 5 : (fused == 2 ? P + 3 : P); }
 
@@ -1256,14 +1338,21 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     if (fused == 1)
         CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && sums1_part,
                     "ctn_dw_bwd: fused mode needs every norm argument");
-    if (fused == 2)         // (ms2 carries the per-frame constants fc [M][4][Kp])
+    const bool xcln = fused == 2 && g1 != nullptr;        // the cLN form with the first norm's output recomputed from Y1 = h1
+    if (fused == 2) {       // (ms2 carries the per-frame constants fc [M][4][Kp]; ms1 / sums2_part the first norm's mean / rstd [M][Kp])
         CTN_REQUIRE(Dz && g2 && a2 && ms2 && aligned16(ms2), "ctn_dw_bwd_cln: null or unaligned argument");
+        CTN_REQUIRE(!xcln || (b1 && a1 && ms1 && sums2_part && aligned16(ms1) && aligned16(sums2_part)), "ctn_dw_bwd_cln: incomplete first-norm arguments");
+    }
     DwBwdArgs a{};
     a.dN2 = dN2; a.Dz = Dz; a.Y1 = Y1; a.dN1 = dN1; a.D = D;
     a.M = M; a.H = H; a.K = K; a.Kp = Kp; a.P = P; a.dil = dilation; a.padl = causal ? halo : halo / 2; a.seg = seg;
     a.g1 = g1; a.b1 = b1; a.a1 = a1; a.ms1 = ms1; a.g2 = g2; a.a2 = a2; a.ms2 = ms2;
     a.sums2_part = sums2_part; a.sums2_nparts = sums2_nparts; a.pc = pc; a.sums1_part = sums1_part;
-    if (fused == 2) { a.fc2 = ms2; a.ms2 = nullptr; }
+    if (fused == 2) {
+        a.fc2 = ms2; a.ms2 = nullptr;
+        if (xcln) { a.mean1f = ms1; a.rstd1f = reinterpret_cast<const float*>(sums2_part); }
+        a.ms1 = nullptr; a.sums2_part = nullptr; a.sums2_nparts = 0;
+    }
     const dim3 grid((unsigned)(M * ctn_cdiv(H, ROWS))), block(NT);
     hipStream_t st = (hipStream_t)stream;
     // float4 compute path whenever the tap offsets keep 16-byte alignment (dilation and left pad multiples of 4): with the
@@ -1284,6 +1373,7 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
         else CTN_DW_BWD_P(D_, X_, 0);         \
     } while (0)
     if (fused == 1) CTN_DW_BWD(1, 1);
+    else if (xcln) CTN_DW_BWD(2, 2);
     else if (fused == 2) CTN_DW_BWD(2, 0);
     else CTN_DW_BWD(0, 0);
 #undef CTN_DW_BWD_P
@@ -1308,9 +1398,12 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
 // cLN form (round 4): see include/ctn_hip.h
 int ctn_dw_bwd_cln(const float* dN2, const float* Dz, const float* X1, float* dN1, const float* D,
                    int M, int H, int K, int Kp, int P, int dilation, int causal,
-                   const float* g2, const float* a2, const float* fc, float* pc, void* stream) {
-    return ctn_dw_bwd(dN2, Dz, X1, dN1, D, M, H, K, Kp, P, dilation, causal, 2, nullptr, nullptr, nullptr, nullptr, g2, a2, fc,
-                      nullptr, 0, pc, nullptr, stream);
+                   const float* g2, const float* a2, const float* fc,
+                   const float* g1, const float* b1, const float* a1, const float* mean1, const float* rstd1,
+                   float* pc, void* stream) {
+    CTN_REQUIRE((g1 == nullptr) == (mean1 == nullptr) && (g1 == nullptr) == (rstd1 == nullptr), "ctn_dw_bwd_cln: first-norm arguments come together");
+    return ctn_dw_bwd(dN2, Dz, X1, dN1, D, M, H, K, Kp, P, dilation, causal, 2, g1, b1, a1, mean1, g2, a2, fc,
+                      reinterpret_cast<const double*>(rstd1), 0, pc, nullptr, stream);
 }
 
 int ctn_dw_bwd_cln_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2, float* dalpha2,
@@ -1330,6 +1423,15 @@ int ctn_cln_bwd_frame(const double* col_part, int nparts, const float* mean, con
     hipLaunchKernelGGL(cln_bwd_frame_kernel, dim3((unsigned)ctn_cdivll((long long)M * Kp, NT)), dim3(NT), 0, (hipStream_t)stream,
                        col_part, nparts, mean, rstd, fc, M, Ch, Kp);
     CTN_CHECK_LAUNCH("ctn_cln_bwd_frame");
+    return CTN_OK;
+}
+
+int ctn_cln_stats_frame(const double* col_part, int nparts, float* mean, float* rstd, int M, int Ch, int Kp, void* stream) {
+    CTN_REQUIRE(col_part && mean && rstd && nparts > 0 && M > 0 && Ch > 0 && Kp > 0, "ctn_cln_stats_frame: bad arguments");
+    CTN_REQUIRE(aligned16(col_part), "ctn_cln_stats_frame: col_part must be 16-byte aligned");
+    hipLaunchKernelGGL(cln_stats_frame_kernel, dim3((unsigned)ctn_cdivll((long long)M * Kp, NT)), dim3(NT), 0, (hipStream_t)stream,
+                       col_part, nparts, mean, rstd, M, Ch, Kp);
+    CTN_CHECK_LAUNCH("ctn_cln_stats_frame");
     return CTN_OK;
 }
 
@@ -1367,7 +1469,7 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
 // (512 threads); ctn_tune("cln_fr", 16 | 32).  The backward partial buffers are sized and summed by this count for every kernel
 // of the family.
 int g_ctn_cln_fr = 16;
-int g_ctn_cln_fuse = 1;          // ctn_tune("cln_fuse", 0 | 1): composite cLN stacks run the second norm's backward inside the input-gradient
+int g_ctn_cln_fuse = 2;          // ctn_tune("cln_fuse", 0 | 1 | 2): 1 = composite cLN stacks run the second norm's backward inside the input-gradient
                                  // GEMM's epilogue (per-frame sums) and the depthwise backward's dd image instead of as a pass of its own
 int ctn_cln_fuse(void) { return g_ctn_cln_fuse; }
 int g_ctn_cln_lean = 1;          // ctn_tune("cln_lean", 0 | 1): the specialised backward kernel for the stacks' form

@@ -269,6 +269,44 @@ def pw_dgrad_cln(W, dOut, R, Cn, K, y, gamma, alpha, mean, rstd, g_amax=None):
     return dn, part
 
 
+def pw_gemm_cln(W, X, R, Cn, K, alpha, x_amax=None):
+    """ctn_pw_gemm_cln: Out = W . X (W stored [R, Cn]) + the per-frame column partials of (sum p, sum p^2), p = prelu(Out, alpha), on
+    the weight form the composite stack uses.  Returns (Out, col_part [M, nparts, Kp, 2] f64)."""
+    M, _, Kp = X.shape
+    if x_amax is not None:
+        Wp, form = h3_pieces(W, R, Cn, False), 3
+    elif _b3_planes_ok(R):
+        Wp, form = _b3_pieces(W, R, Cn, False), 2
+    else:
+        Wp, form = W.reshape(R, Cn).t().contiguous(), 1          # the composite's [I, O] copy (ctn_transpose_batch)
+    out = torch.empty((M, R, Kp), dtype=F32, device=X.device)
+    part = torch.empty((M, lib.ctn_pw_col_parts(M, R, Kp, form), Kp, 2), dtype=F64, device=X.device)
+    _chk(X, alpha)
+    _chk_aux(x_amax)
+    lib.call("ctn_pw_gemm_cln", _p(Wp), form, _p(X), _p(out), M, R, Cn, K, Kp, _p(alpha), _p(part), _p(x_amax), _stream())
+    return out, part
+
+
+def cln_stats_frame(col_part, Ch):
+    """ctn_cln_stats_frame: (mean, rstd) [M, Kp] of a channel-wise LayerNorm from ctn_pw_gemm_cln's column partials."""
+    M, nparts, Kp, _ = col_part.shape
+    mean = torch.empty((M, Kp), dtype=F32, device=col_part.device)
+    rstd = torch.empty((M, Kp), dtype=F32, device=col_part.device)
+    _chk_aux(col_part)
+    lib.call("ctn_cln_stats_frame", _p(col_part), nparts, _p(mean), _p(rstd), M, Ch, Kp, _stream())
+    return mean, rstd
+
+
+def dw_fwd_cln(Y, D, K, dilation, causal, mean, rstd, gamma, beta, alpha):
+    """ctn_dw_fwd_cln: depthwise conv of cLN(prelu(Y)) with the norm applied in the prologue (per-frame statistics)."""
+    M, H, Kp = Y.shape
+    Z = torch.empty_like(Y)
+    _chk(Y, D, mean, rstd, gamma, beta, alpha)
+    lib.call("ctn_dw_fwd_cln", _p(Y), _p(Z), _p(D), M, H, K, Kp, D.shape[-1], dilation, int(causal), _p(mean), _p(rstd), _p(gamma),
+             _p(beta), _p(alpha), _stream())
+    return Z
+
+
 def cln_bwd_frame(col_part, mean, rstd, Ch):
     """ctn_cln_bwd_frame: fc [M, 4, Kp] = (rstd, mean rstd, rstd S1/Ch, rstd S2/Ch) per frame from ctn_pw_dgrad_cln's partials."""
     M, nparts, Kp, _ = col_part.shape
@@ -279,17 +317,19 @@ def cln_bwd_frame(col_part, mean, rstd, Ch):
     return fc
 
 
-def dw_bwd_cln(dn2, d, n1, D, K, dilation, causal, g2, a2, fc, sinks=None):
+def dw_bwd_cln(dn2, d, n1, D, K, dilation, causal, g2, a2, fc, sinks=None, norm1=None):
     """ctn_dw_bwd_cln + ctn_dw_bwd_cln_finalize: cLN2 <- PReLU2 <- depthwise backward in one pass.
-    -> dn1, dD [H,1,P], dgamma2 [H], dbeta2 [H], dalpha2 [1]; sinks = (dD, dgamma2, dbeta2, dalpha2) destinations or None."""
+    -> dn1, dD [H,1,P], dgamma2 [H], dbeta2 [H], dalpha2 [1]; sinks = (dD, dgamma2, dbeta2, dalpha2) destinations or None.
+    norm1 = (g1, b1, a1, mean1, rstd1): `n1` is then the first norm's INPUT h1 and its output is recomputed in the kernel."""
     M, H, Kp = d.shape
     P = D.shape[-1]
     dev = d.device
     pc = torch.empty((P + 3, M, H), dtype=F32, device=dev)
     dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
-    _chk(dn2, d, n1, D, g2, a2, fc)
+    n1a = (None,) * 5 if norm1 is None else norm1
+    _chk(dn2, d, n1, D, g2, a2, fc, *n1a)
     lib.call("ctn_dw_bwd_cln", _p(dn2), _p(d), _p(n1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), _p(g2), _p(a2), _p(fc),
-             _p(pc), _stream())
+             _p(n1a[0]), _p(n1a[1]), _p(n1a[2]), _p(n1a[3]), _p(n1a[4]), _p(pc), _stream())
     if sinks is None:
         dD = torch.empty((H, 1, P), dtype=F32, device=dev)
         dg, db, da = (torch.empty((H,), dtype=F32, device=dev), torch.empty((H,), dtype=F32, device=dev),
@@ -890,13 +930,20 @@ class ClnBlock(torch.autograd.Function):
         if H % 4 or B % 4:
             raise ValueError("HIP path needs B and H to be multiples of 4")
         h3 = _h3_block(B, H)       # the composite stack's arithmetic, kernel by kernel (maxima measured here: exact, so the same bits)
-        if h3:
-            ax = absmax_rows(x)
-            h1, _ = pw_gemm_h3(h3_pieces(w1, H, B, False), x, H, B, K, ax)
+        fuse1 = lib.ctn_cln_fuse() >= 2     # the first norm without a pass (the composite's rule): statistics from K1's epilogue, applied in K2's prologue
+        ax = absmax_rows(x) if h3 else None
+        if fuse1:
+            h1, colp = pw_gemm_cln(w1, x, H, B, K, a1, x_amax=ax)
+            mean1, rstd1 = cln_stats_frame(colp, H)
+            d = dw_fwd_cln(h1, D, K, dilation, causal, mean1, rstd1, g1, b1, a1)
+            n1 = h1.new_empty(0)                    # never stored
         else:
-            h1, _ = pw_gemm(w1, x, H, B, K)
-        n1, mean1, rstd1 = cln_fwd(h1, g1, b1, a1, K)
-        d, _ = dw_fwd(n1, D, K, dilation, causal)
+            if h3:
+                h1, _ = pw_gemm_h3(h3_pieces(w1, H, B, False), x, H, B, K, ax)
+            else:
+                h1, _ = pw_gemm(w1, x, H, B, K)
+            n1, mean1, rstd1 = cln_fwd(h1, g1, b1, a1, K)
+            d, _ = dw_fwd(n1, D, K, dilation, causal)
         n2, mean2, rstd2 = cln_fwd(d, g2, b2, a2, K)
         if h3:
             an = absmax_rows(n2)
@@ -904,14 +951,15 @@ class ClnBlock(torch.autograd.Function):
         else:
             out, _ = pw_gemm(w2, n2, B, H, K, residual=x)
         ctx.h3 = (ax, an) if h3 else None
-        ctx.save_for_backward(x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2)
+        ctx.save_for_backward(x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2, b1)
         ctx.cfg = (K, dilation, causal)
+        ctx.fuse1 = fuse1
         ctx.sinks = tuple(_sink(p) for p in (w1, a1, g1, b1, D, a2, g2, b2, w2))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2 = ctx.saved_tensors
+        x, h1, n1, d, n2, mean1, rstd1, mean2, rstd2, w1, a1, g1, D, a2, g2, w2, b1 = ctx.saved_tensors
         K, dilation, causal = ctx.cfg
         dout = _c(dout)
         M, B, Kp = x.shape
@@ -927,7 +975,7 @@ class ClnBlock(torch.autograd.Function):
         # 21.7 ms/step at paper size (CONFIG=causal benchmarks/ab_step.py).  CTN_CLN_SIDE=0 turns it off.
         side = direct and _SIDE_ENABLED and _CLN_SIDE
         h3 = ctx.h3
-        fuse = lib.ctn_cln_fuse() != 0          # the second norm's backward inside the GEMM epilogue + the depthwise backward (the composite's rule)
+        fuse = lib.ctn_cln_fuse() != 0 or ctx.fuse1     # the second norm's backward inside the GEMM epilogue + the depthwise backward (the composite's rule)
         ady = None
         if h3 is not None:
             ax, an = h3
@@ -947,8 +995,9 @@ class ClnBlock(torch.autograd.Function):
             dW2 = pw_wgrad(dout, n2, B, H, K, out=sk[8] if direct else None)
         if fuse:
             fc = cln_bwd_frame(colp, mean2, rstd2, H)
-            dn1, dD, dg2, db2, da2 = dw_bwd_cln(dn2, d, n1, D, K, dilation, causal, g2, a2, fc,
-                                                sinks=(sk[4], sk[6], sk[7], sk[5]) if direct else None)
+            dn1, dD, dg2, db2, da2 = dw_bwd_cln(dn2, d, h1 if ctx.fuse1 else n1, D, K, dilation, causal, g2, a2, fc,
+                                                sinks=(sk[4], sk[6], sk[7], sk[5]) if direct else None,
+                                                norm1=(g1, b1, a1, mean1, rstd1) if ctx.fuse1 else None)
         else:
             dd, dg2, db2, da2 = cln_bwd(dn2, d, mean2, rstd2, g2, a2, K, sinks=(sk[6], sk[7], sk[5]) if direct else None)
             pc = torch.empty((P, M, H), dtype=F32, device=dev)

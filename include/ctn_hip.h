@@ -92,9 +92,11 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * kernel (16: three 256-thread workgroups per CU; changes ctn_cln_bwd_blocks()); "cln_lean" 0|1 (default 1): ctn_cln_bwd at 512 channels with PReLU and without `add` /
  * `relu_ref` runs a kernel specialised for that form (same bits, 11 % faster alone); "wgrad_chain" 0|1 (default 0): inside the
  * composite stacks the split-K slabs of a weight gradient are summed by the NEXT weight-gradient launch of the stream instead of a
- * slab_reduce launch of their own (same addition order, same bits; measured equal in the step); "cln_fuse" 0|1 (default 1): the
+ * slab_reduce launch of their own (same addition order, same bits; measured equal in the step); "cln_fuse" 0|1|2 (default 2): 1 = the
  * composite cLN stacks run the second norm's backward inside the input-gradient GEMM's epilogue and the depthwise backward
- * (ctn_pw_dgrad_cln / ctn_cln_bwd_frame / ctn_dw_bwd_cln) instead of as a ctn_cln_bwd pass; ctn_cln_fuse() reads it.  Defaults are the
+ * (ctn_pw_dgrad_cln / ctn_cln_bwd_frame / ctn_dw_bwd_cln) instead of as a ctn_cln_bwd pass; 2 = also the first norm's forward
+ * inside the first 1x1 conv's epilogue and the depthwise kernel's prologue (ctn_pw_gemm_cln / ctn_cln_stats_frame / ctn_dw_fwd_cln:
+ * n1s is then neither written nor read; set it between steps, forward and backward under the same value); ctn_cln_fuse() reads it.  Defaults are the
  * measured best. */
 int ctn_tune(const char* key, int value);
 int ctn_cln_fuse(void);
@@ -207,12 +209,16 @@ int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* strea
 /* cLN form of the backward (round 4; ChannelwiseLayerNorm, src/conv_tasnet.py:313-335, on the causal config's blocks :257-266):
  * walks  cLN2 <- PReLU2 <- depthwise  in one pass, i.e. the second norm's whole backward rides in the depthwise kernel:
  *   in : dN2 (grad of cLN2's output, from ctn_pw_dgrad_cln), Dz (= Z of the forward = cLN2's input), X1 (= the forward's input =
- *        cLN1's output), gamma2 / alpha2, fc [M][4][Kp] per-frame constants from ctn_cln_bwd_frame
+ *        cLN1's output), gamma2 / alpha2, fc [M][4][Kp] per-frame constants from ctn_cln_bwd_frame;
+ *        g1 != NULL: the first norm's output was never stored -- X1 is its INPUT (the first 1x1 conv's output) and the kernel recomputes
+ *        cLN1(prelu(X1, a1)) from (g1, b1, a1) and the per-frame statistics mean1, rstd1 [M,Kp]; else pass NULL for all five
  *   out: dN1 (grad of X1) and pc [P+3, M, H]: rows 0..P-1 dD taps, P: dgamma2, P+1: dbeta2, P+2: dalpha2 partials
  *        (ctn_dw_bwd_rows(P, 2) rows), finished in fixed order by ctn_dw_bwd_cln_finalize: dD [H,P], dgamma2 / dbeta2 [H], dalpha2 [1]. */
 int ctn_dw_bwd_cln(const float* dN2, const float* Dz, const float* X1, float* dN1, const float* D,
                    int M, int H, int K, int Kp, int P, int dilation, int causal,
-                   const float* g2, const float* a2, const float* fc, float* pc, void* stream);
+                   const float* g2, const float* a2, const float* fc,
+                   const float* g1, const float* b1, const float* a1, const float* mean1, const float* rstd1,
+                   float* pc, void* stream);
 int ctn_dw_bwd_cln_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2, float* dalpha2,
                             void* stream);
 
@@ -326,6 +332,17 @@ int ctn_pw_dgrad_cln(const void* W, int w_form, const float* dOut, float* dN, in
                      const float* y, const float* gamma, const float* alpha, const float* mean, const float* rstd,
                      double* col_part, const unsigned* g_amax, void* stream);
 int ctn_pw_col_parts(int M, int R, int Kp, int w_form);
+/* cLN forward WITHOUT a pass of its own (round 4), for the norm between the first 1x1 conv and the depthwise conv
+ * (src/conv_tasnet.py:223-225 with norm_type = 'cLN'): ctn_pw_gemm_cln is the 1x1 conv Out = op(W) . X that also leaves, per frame,
+ * (sum_c p, sum_c p^2), p = prelu(Out, alpha), as column partials of its row tiles (col_part as above; w_form 0 = fp32 [R, Cn],
+ * 1 = fp32 [Cn, R] used transposed, 2 = b6 pieces, 3 = h3 pieces with x_amax = tracked maximum of X); ctn_cln_stats_frame sums them
+ * over the row tiles into mean, rstd [M,Kp] (fp64, biased variance, eps as ctn_cln_fwd); ctn_dw_fwd_cln is ctn_dw_fwd with
+ * n = gamma ((prelu(Y, alpha) - mean[k]) rstd[k]) + beta applied while the row is staged: the norm's output is never stored. */
+int ctn_pw_gemm_cln(const void* W, int w_form, const float* X, float* Out, int M, int R, int Cn, int K, int Kp,
+                    const float* alpha, double* col_part, const unsigned* x_amax, void* stream);
+int ctn_cln_stats_frame(const double* col_part, int nparts, float* mean, float* rstd, int M, int Ch, int Kp, void* stream);
+int ctn_dw_fwd_cln(const float* Y, float* Z, const float* D, int M, int H, int K, int Kp, int P, int dilation, int causal,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, const float* alpha, void* stream);
 int ctn_cln_bwd_frame(const double* col_part, int nparts, const float* mean, const float* rstd, float* fc, int M, int Ch, int Kp,
                       void* stream);
 /* One launch that finishes the partials above in fixed order: dgamma[Ch], dbeta[Ch] from pc, and dalpha[1] from

@@ -201,28 +201,56 @@ def _cln_block_grads(B, H, K, M, dil, causal, fuse, seed=3):
         out = blk.fused(x, K)           # ops.ClnBlock
         dout = pad(torch.randn(M, B, K, generator=gen), Kp).to(DEV)
         out.backward(dout)
-        return [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+        return [x.grad.clone(), out.detach().clone()] + [p.grad.clone() for p in blk.parameters()]
     finally:
-        ctn.lib.call("ctn_tune", b"cln_fuse", 1)
+        ctn.lib.call("ctn_tune", b"cln_fuse", 2)
 
 
 @pytest.mark.parametrize("B,H,K,M,dil,causal", [(16, 32, 300, 2, 2, True), (64, 128, 799, 2, 8, True), (256, 512, 1300, 2, 128, True),
                                                  (64, 136, 257, 3, 1, False)])
 def test_fused_cln_backward_equals_the_standalone_pass(B, H, K, M, dil, causal):
-    """Round 4: the second norm's backward of a cLN block runs inside the input-gradient GEMM's epilogue (per-frame sums over
-    channels, ctn_pw_dgrad_cln), ctn_cln_bwd_frame and the depthwise backward's dd image (ctn_dw_bwd_cln) instead of as a
-    ctn_cln_bwd pass.  Same mathematics, other summation order: every gradient of the block agrees with the un-fused chain to a
-    few fp32 roundings, under every arithmetic (narrow layers: fp32-MFMA kernels; wide: pieces)."""
-    a = _cln_block_grads(B, H, K, M, dil, causal, True)
-    b = _cln_block_grads(B, H, K, M, dil, causal, False)
-    for i, (u, v) in enumerate(zip(a, b)):
-        assert rel_err(u, v) < 2e-5, i
-    # pad frames of the input gradient stay exact zeros
-    assert float(a[0][..., K:].abs().max()) == 0.0
-    # and the fused chain is bitwise reproducible (fixed-order sums)
-    c = _cln_block_grads(B, H, K, M, dil, causal, True)
-    for u, v in zip(a, c):
-        assert torch.equal(u, v)
+    """Round 4, ctn_tune("cln_fuse"): 1 = the second norm's backward of a cLN block runs inside the input-gradient GEMM's epilogue
+    (per-frame sums over channels, ctn_pw_dgrad_cln), ctn_cln_bwd_frame and the depthwise backward's dd image (ctn_dw_bwd_cln) instead
+    of as a ctn_cln_bwd pass; 2 (default) = also the first norm's forward: statistics from the first 1x1 conv's epilogue
+    (ctn_pw_gemm_cln, ctn_cln_stats_frame), the norm applied in the depthwise kernels' prologues (ctn_dw_fwd_cln; backward recomputes
+    it from h1), its output never stored.  Same mathematics, other summation order: the block's output and every gradient agree with
+    the un-fused chain (0) to a few fp32 roundings, under every arithmetic (narrow layers: fp32-MFMA kernels; wide: pieces)."""
+    ref = _cln_block_grads(B, H, K, M, dil, causal, 0)
+    for level in (1, 2):
+        a = _cln_block_grads(B, H, K, M, dil, causal, level)
+        for i, (u, v) in enumerate(zip(a, ref)):
+            assert rel_err(u, v) < 2e-5, (level, i)
+        # pad frames of the output and of the input gradient stay exact zeros
+        assert float(a[0][..., K:].abs().max()) == 0.0 and float(a[1][..., K:].abs().max()) == 0.0
+        # and the fused chain is bitwise reproducible (fixed-order sums)
+        c = _cln_block_grads(B, H, K, M, dil, causal, level)
+        for u, v in zip(a, c):
+            assert torch.equal(u, v)
+
+
+def test_cln_forward_statistics_from_the_gemm_epilogue_against_fp64():
+    """ctn_pw_gemm_cln + ctn_cln_stats_frame against fp64 torch: Out, and (mean, rstd) per frame of prelu(Out) over channels."""
+    M, R, Cn, K = 2, 192, 64, 333
+    gen = g(12)
+    Kp = ops.padded_frames(K)
+    W = torch.randn(R, Cn, generator=gen) * 0.2
+    X = pad(torch.randn(M, Cn, K, generator=gen), Kp)
+    X[1] *= 1e-3                                    # a quiet utterance: eps matters less than the variance there, but the scale differs
+    alpha = torch.tensor([0.25])
+    h3 = ARITH["name"] == "h3"
+    amax = ops.absmax_rows(X.to(DEV)) if h3 else None
+    out, colp = ops.pw_gemm_cln(W.to(DEV), X.to(DEV), R, Cn, K, alpha.to(DEV), x_amax=amax)
+    mean, rstd = ops.cln_stats_frame(colp, R)
+    o64 = torch.einsum("rc,mck->mrk", W.double(), X.double())
+    p = torch.where(o64 >= 0, o64, 0.25 * o64)
+    mu = p.mean(dim=1)
+    rs = 1.0 / torch.sqrt(((p - mu[:, None]) ** 2).mean(dim=1) + 1e-8)
+    for m in range(M):      # per utterance: the scales differ by 1e3
+        assert rel_err(out[m, :, :K], o64[m, :, :K]) < 5e-6
+        assert rel_err(mean[m, :K], mu[m, :K]) < 2e-5
+        assert rel_err(rstd[m, :K], rs[m, :K]) < 2e-5
+    # pad frames: all-zero columns -> mean 0, rstd 1 / sqrt(eps)
+    assert float(mean[:, K:].abs().max()) == 0.0 and abs(float(rstd[0, K]) - 1e4) < 1.0
 
 
 def test_cln_backward_entry_points_against_fp64():
