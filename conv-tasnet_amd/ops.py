@@ -829,7 +829,9 @@ def tcn_cln_infer(x0, K, dilations, causal, params):
     dev = x0.device
     _chk(x0, *params)
     xs = torch.empty((2, M, B, Kp), dtype=F32, device=dev)
-    h = torch.empty((4, M, H, Kp), dtype=F32, device=dev)
+    fuse1 = lib.ctn_cln_fuse() >= 2
+    h = torch.empty((3 if fuse1 else 4, M, H, Kp), dtype=F32, device=dev)
+    h = (h[0], h[0], h[1], h[2]) if fuse1 else (h[0], h[1], h[2], h[3])
     st = torch.empty((4, M, Kp), dtype=F32, device=dev)
     amax = torch.empty((nb, 2, M, AMAX_SLOTS), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked operand maxima (zeroed by the call)
     nbytes = lib.ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nb)
@@ -857,7 +859,9 @@ class TcnCln(torch.autograd.Function):
         dev = x0.device
         _chk(x0, *params)
         xs = torch.empty((nb, M, B, Kp), dtype=F32, device=dev)
-        hs = torch.empty((4, nb, M, H, Kp), dtype=F32, device=dev)          # h1, n1, d, n2
+        fuse1 = lib.ctn_cln_fuse() >= 2            # the first norm's output is neither written nor read (include/ctn_hip.h, "cln_fuse")
+        hs = torch.empty((3 if fuse1 else 4, nb, M, H, Kp), dtype=F32, device=dev)          # h1, [n1,] d, n2
+        hs = (hs[0], hs[0], hs[1], hs[2]) if fuse1 else (hs[0], hs[1], hs[2], hs[3])          # (n1s must be a valid pointer: never touched when fused)
         st = torch.empty((nb, 4, M, Kp), dtype=F32, device=dev)            # mean1, rstd1, mean2, rstd2
         amax = torch.empty((nb, 2, M, AMAX_SLOTS), dtype=torch.int32, device=dev)     # h3 arithmetic: tracked maxima of every block's input / second norm output
         nbytes = lib.ctn_tcn_cln_fwd_workspace(M, B, H, Kp, nb)
@@ -881,7 +885,7 @@ class TcnCln(torch.autograd.Function):
         K, dil, nb, causal, P = ctx.cfg
         dout = _c(dout)
         _, M, B, Kp = xs.shape
-        H = hs.shape[3]
+        H = hs[0].shape[2]
         dev = x0.device
         _chk(dout)
         direct = all(s is not None for s in ctx.sinks)
