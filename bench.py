@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+_T_PROC = time.time()         # the driver's clock runs from process start: the CPU leg is bounded against it (WALL_LIMIT_S)
+WALL_LIMIT_S = 540.0          # whole default run, import torch on a cold box included (the driver allows 600 s)
+
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)" (154.5 measured on the box:
                                # benchmarks/mfma_probe.hip, profiles/r02_a_mfma_probe.txt)
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
@@ -110,6 +113,9 @@ def _host_cpu():
 
 
 def cpu_baseline(cfg, budget_s=240.0):
+    # never past the whole-run limit: what is left of it, minus the 8-thread leg (~3 steps) -- at least 3 timed steps are taken
+    left = WALL_LIMIT_S - (time.time() - _T_PROC)
+    budget_s = max(60.0, min(budget_s, left - 150.0))
     """The oracle (torch CPU restatement of the reference step: fwd + loss + bwd + clip(5) + Adam) on this host, batch 8,
     all physical cores this process may use; then the same on 8 threads (the survey container's count).  BASELINE.md section 4:
     3 warm-up + >= 10 timed steps, median and min.  A paper-config step takes ~20 s on a 1-GPU box's 16-core share, so the
@@ -133,7 +139,8 @@ def cpu_baseline(cfg, budget_s=240.0):
                 warm += 1                      # allocator, thread pool, first-touch of 18 GB of saved activations
                 continue
             times.append(dt)
-            if len(times) >= max_steps or (len(times) >= min_steps and elapsed + dt > budget):
+            if len(times) >= max_steps or (len(times) >= min_steps and elapsed + dt > budget) or \
+                    (len(times) >= 3 and time.time() - _T_PROC + dt > WALL_LIMIT_S - 60.0):
                 return warm, times
 
     warm, times = run(cores, budget_s, 3, 5, 10)
@@ -147,7 +154,7 @@ def cpu_baseline(cfg, budget_s=240.0):
                      "core usable by the process: min of physical cores, affinity mask, cgroup quota), wall budget %.0f s; "
                      "value = batch / median step time"
                      % (len(times), PER_GPU_BATCH, warm, cores, budget_s)}
-    if cores != 8:
+    if cores != 8 and time.time() - _T_PROC + 3.5 * med < WALL_LIMIT_S:
         w8, t8 = run(min(8, cores), budget_s * 0.2, 1, 2, 3)
         out["threads8"] = {"value": round(PER_GPU_BATCH / statistics.median(t8), 4), "timed_steps": len(t8), "warmup_steps": w8,
                            "threads": min(8, cores), "min_s_per_step": round(min(t8), 3)}
@@ -680,6 +687,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+            out["wall_s_since_process_start"] = round(time.time() - _T_PROC, 1)
         print(json.dumps(out), flush=True)
 
 

@@ -67,6 +67,9 @@ extern "C" int ctn_probe_read(int* fam, float* us, int cap) {
     return n;
 }
 
+// lab switch, ctn_tune("exp_skip", mask): TIMING experiments only (results are wrong): bit 0 = the gLN stack's backward skips B4
+int g_ctn_exp_skip = 0;
+
 namespace {
 
 enum { P_W1 = 0, P_A1, P_G1, P_B1, P_D, P_A2, P_G2, P_B2, P_W2, NPARAM };
@@ -349,7 +352,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         // gLN1' / PReLU1' backward in place (B4).  (Folding it into the operand prologues of its two consumers was built and
         // measured in round 2: 10.23 vs 10.13 ms per step with B4 as its own pass -- both GEMMs then read h1 as well.)
         const int n_da1 = M * H;
-        rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, h3 ? adh : nullptr, stream));
+        if (!(g_ctn_exp_skip & 1)) rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, h3 ? adh : nullptr, stream));
+        else if (h3) rc = ctn_absmax_rows(dn1, M, (long long)H * Kp, adh, stream);        // (lab: keep the h3 scales finite)
         if (rc) return rc;
         // first 1x1; the weight gradient and the fixed-order sums of this block's parameter-gradient partials feed only the
         // optimiser: second stream

@@ -393,6 +393,36 @@ def test_composite_stack_is_bitwise_the_per_kernel_path(flat, causal, norm_type,
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_cln_composite_is_bitwise_the_per_kernel_path_at_every_fusion_level(level, monkeypatch):
+    """The same for the cLN stack under ctn_tune("cln_fuse", 0 | 1) (2, the default, is covered above): the un-fused norm passes
+    and the backward-only fusion stay selectable, and the composite and ops.ClnBlock follow the same rule."""
+    from conv_tasnet_amd import ops
+    mix, lens, src = O.synth_batch(5, 3, 4000 + 7)
+    ctn.lib.call("ctn_tune", b"cln_fuse", level)
+    try:
+        res = []
+        for composite in (True, False):
+            monkeypatch.setattr(ops, "_COMPOSITE", composite)
+            torch.manual_seed(3)
+            m = ctn.ConvTasNet(64, 20, 64, 128, 3, 3, 2, 2, norm_type="cLN", causal=True).to(DEV)
+            opt = FlatAdam(m.parameters(), lr=1e-3)
+            opt.zero_grad()
+            est = m(mix.to(DEV))
+            loss = ctn.cal_loss(src.to(DEV), est, lens.to(DEV))[0]
+            loss.backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append((est.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        (e1, l1, g1), (e2, l2, g2) = res
+        assert torch.equal(e1, e2) and torch.equal(l1, l2)
+        for a, b in zip(g1, g2):
+            assert torch.equal(a, b)
+    finally:
+        ctn.lib.call("ctn_tune", b"cln_fuse", 2)
+        ops._ws_cache.clear()
+
+
 def test_evaluate_with_the_reference_signature(tmp_path, capsys):
     """evaluate(model_path, data_dir, calc_sdr, use_cuda, sample_rate, batch_size), src/evaluate.py:21: checkpoint file +
     {mix,s1,s2}.json manifests of wav files in, average SI-SNRi out; calc_sdr (mir_eval) is an explicit error."""
