@@ -69,6 +69,11 @@ extern "C" int ctn_probe_read(int* fam, float* us, int cap) {
 
 // lab switch, ctn_tune("exp_skip", mask): TIMING experiments only (results are wrong): bit 0 = the gLN stack's backward skips B4
 int g_ctn_exp_skip = 0;
+// ctn_tune("bwd_events", 1 | 2): cross-stream events per block of the backward pass.  2 (rounds 1-4): the second 1x1 conv's weight
+// gradient is forked behind B1, the first one's behind B4.  1: ONE fork per block, behind B5 -- dW2 of block i needs only dy_i (the
+// output of B5 of block i+1) and forward tensors, so it rides behind the event that releases dW1 of block i+1; each event costs the
+// main chain ~5 us (profiles/README.md r04_k).
+int g_ctn_bwd_events = 2;
 
 namespace {
 
@@ -318,6 +323,23 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         }
         if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
     }
+    const bool one_event = side_stream != nullptr && g_ctn_bwd_events == 1;
+    // the second 1x1 conv's weight gradient of block j: dW2 = dy_j . gLN2(prelu(d_j))^T -- it needs dy_j and forward tensors only
+    auto wgrad2 = [&](int j) -> int {
+        const float* const* pj = (const float* const*)(params + (size_t)j * NPARAM);
+        float* const* gj = (float* const*)(grads + (size_t)j * NPARAM);
+        const float* const dj = ds + (size_t)j * hsz;
+        const float* const dyj = j == nblocks - 1 ? dout : dxs + (size_t)(j + 1) * xsz;
+        const float* const ms2j = ms + ((size_t)j * 2 + 1) * M * 2;
+        const unsigned* const adj = h3 ? amax + (size_t)(2 * j + 1) * M * CTN_AMAX_SLOTS : nullptr;
+        unsigned* const adyj = amax_b + (size_t)(2 * j) * M * CTN_AMAX_SLOTS;
+        if (h3) return PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dyj, dj, gj[P_W2], M, B, H, K, Kp, pj[P_G2], pj[P_B2], pj[P_A2], ms2j, adyj, adj, gb + 2 * j, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+        return PROBED(F_B2, wst, ctn_pw_wgrad_chained(dyj, dj, gj[P_W2], M, B, H, K, Kp, pj[P_G2], pj[P_B2], pj[P_A2], ms2j, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+    };
+    if (one_event) {        // dout, its maximum and the norm parameters' maxima are ready in stream order: the last block's dW2 can start
+        if ((rc = ctn_stream_order(stream, side_stream))) return rc;
+        if ((rc = wgrad2(nblocks - 1))) return rc;
+    }
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
@@ -341,10 +363,10 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         else if (twh == 2) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         else rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         if (rc) return rc;
-        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, ady, ad, gb + 2 * i, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
-        else rc = PROBED(F_B2, wst, ctn_pw_wgrad_chained(dy, d, g[P_W2], M, B, H, K, Kp, p[P_G2], p[P_B2], p[P_A2], ms2, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
-        if (rc) return rc;
+        if (!one_event) {
+            if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+            if ((rc = wgrad2(i))) return rc;
+        }
         // gLN2 <- PReLU2 <- depthwise <- gLN1 output in one pass, then gLN1 + PReLU1 backward in place
         rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
                         p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream));
@@ -357,7 +379,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         if (rc) return rc;
         // first 1x1; the weight gradient and the fixed-order sums of this block's parameter-gradient partials feed only the
         // optimiser: second stream
-        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+        if (side_stream && !one_event && (rc = ctn_stream_order(stream, side_stream))) return rc;
         auto wgrad1 = [&]() -> int {
             if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3_chained(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
             return PROBED(F_B6, wst, ctn_pw_wgrad_chained(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
@@ -365,7 +387,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         auto finalize = [&](void* st) -> int {
             return PROBED(F_FIN, st, ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st));
         };
-        if (side_stream) {          // the fixed-order sums feed only the optimiser: second stream, behind the weight gradient
+        if (side_stream && !one_event) {          // the fixed-order sums feed only the optimiser: second stream, behind the weight gradient
             if ((rc = wgrad1())) return rc;
             if ((rc = finalize(wst))) return rc;
         }
@@ -374,6 +396,12 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         else rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dn1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
                          nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
         if (rc) return rc;
+        if (one_event) {            // one fork per block, behind B5: this block's dW1 and sums, then the next block's dW2 (its dy is this B5's output)
+            if ((rc = ctn_stream_order(stream, side_stream))) return rc;
+            if ((rc = wgrad1())) return rc;
+            if ((rc = finalize(wst))) return rc;
+            if (i > 0 && (rc = wgrad2(i - 1))) return rc;
+        }
         if (!side_stream) {
             if ((rc = wgrad1())) return rc;
             if ((rc = finalize(stream))) return rc;
@@ -568,6 +596,20 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         }
         if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
     }
+    const bool one_event = side_stream != nullptr && g_ctn_bwd_events == 1;       // (see ctn_tcn_gln_bwd)
+    auto wgrad2 = [&](int j) -> int {       // dW2 of block j = dy_j . n2_j^T: needs dy_j and forward tensors only
+        float* const* gj = (float* const*)(grads + (size_t)j * NPARAM);
+        const float* const n2j = n2s + (size_t)j * hsz;
+        const float* const dyj = j == nblocks - 1 ? dout : dxs + (size_t)(j + 1) * xsz;
+        const unsigned* const anj = h3 ? amax + (size_t)(2 * j + 1) * M * CTN_AMAX_SLOTS : nullptr;
+        unsigned* const adyj = amax_b + (size_t)(2 * j) * M * CTN_AMAX_SLOTS;
+        if (h3) return PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dyj, n2j, gj[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, adyj, anj, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+        return PROBED(F_B2, wst, ctn_pw_wgrad_chained(dyj, n2j, gj[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
+    };
+    if (one_event) {
+        if ((rc = ctn_stream_order(stream, side_stream))) return rc;
+        if ((rc = wgrad2(nblocks - 1))) return rc;
+    }
     for (int i = nblocks - 1; i >= 0; --i) {
         const float* const* p = (const float* const*)(params + (size_t)i * NPARAM);
         float* const* g = (float* const*)(grads + (size_t)i * NPARAM);
@@ -594,10 +636,10 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         else rc = PROBED(F_B1, stream, ctn_pw_gemm(twh == 2 ? (const float*)(wreg + (size_t)(2 * i) * slot) : p[P_W2], dy, dn2, M, H, B, K, Kp, twh == 2 ? 2 : 1,
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream));
         if (rc) return rc;
-        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        if (h3) rc = PROBED(F_B2, wst, ctn_pw_wgrad_h3_chained(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, ady, an, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
-        else rc = PROBED(F_B2, wst, ctn_pw_wgrad_chained(dy, n2, g[P_W2], M, B, H, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
-        if (rc) return rc;
+        if (!one_event) {
+            if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+            if ((rc = wgrad2(i))) return rc;
+        }
         if (fuse) {
             if ((rc = PROBED(F_FRAME, stream, ctn_cln_bwd_frame(colp, w.ncol, stb + 2 * ssz, stb + 3 * ssz, fc, M, H, Kp, stream)))) return rc;
             if (fuse1) rc = PROBED(F_B3, stream, ctn_dw_bwd_cln(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, p[P_G2], p[P_A2], fc,
@@ -611,27 +653,38 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
                                  nullptr, nullptr, nullptr, nullptr, 0, pcw, nullptr, stream)))) return rc;
         }
         if ((rc = PROBED(F_CLN_BWD, stream, ctn_cln_bwd(dn1, h1, dh1, stb, stb + ssz, M, H, K, Kp, p[P_G1], p[P_A1], nullptr, nullptr, dap1, pcn1, h3 ? adh : nullptr, stream)))) return rc;
-        if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
-        // the three fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
+        // the fixed-order parameter-gradient sums of this block feed only the optimiser: weight-gradient stream
         void* const fst = wst;
-        if (fuse) {
-            if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_cln_finalize(pcw, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
-        } else {
-            if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return rc;
-            if ((rc = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return rc;
-        }
-        if ((rc = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst)))) return rc;
+        auto fins = [&]() -> int {
+            int r;
+            if (fuse) {
+                if ((r = PROBED(F_TAPS, fst, ctn_dw_bwd_cln_finalize(pcw, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_A2], fst)))) return r;
+            } else {
+                if ((r = PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn2, dap2, M, H, Kp, g[P_G2], g[P_B2], g[P_A2], fst)))) return r;
+                if ((r = PROBED(F_TAPS, fst, ctn_dw_bwd_taps(pcw, P, M, H, g[P_D], fst)))) return r;
+            }
+            return PROBED(F_FIN, fst, ctn_cln_bwd_finalize(pcn1, dap1, M, H, Kp, g[P_G1], g[P_B1], g[P_A1], fst));
+        };
         auto wgrad1 = [&]() -> int {
             if (h3) return PROBED(F_B6, wst, ctn_pw_wgrad_h3_chained(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, adh, ax, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
             return PROBED(F_B6, wst, ctn_pw_wgrad_chained(dh1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         };
-        if (side_stream && (rc = wgrad1())) return rc;
+        if (!one_event) {
+            if (side_stream && (rc = ctn_stream_order(stream, side_stream))) return rc;
+            if ((rc = fins())) return rc;
+            if (side_stream && (rc = wgrad1())) return rc;
+        }
         if (h3) rc = PROBED(F_B5, stream, ctn_pw_gemm_h3(wreg + (size_t)(2 * i + 1) * slot, dh1, dx, M, B, H, K, Kp, nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy,
                               nullptr, nullptr, adh, nullptr, i > 0 ? amax_b + (size_t)(2 * i - 2) * M * CTN_AMAX_SLOTS : nullptr, stream));
         else rc = PROBED(F_B5, stream, ctn_pw_gemm(twb == 2 ? (const float*)(wreg + (size_t)(2 * i + 1) * slot) : p[P_W1], dh1, dx, M, B, H, K, Kp, twb == 2 ? 2 : 1,
                               nullptr, 0, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, stream));
         if (rc) return rc;
-        if (!side_stream && (rc = wgrad1())) return rc;
+        if (one_event) {            // one fork per block, behind B5 (see ctn_tcn_gln_bwd)
+            if ((rc = ctn_stream_order(stream, side_stream))) return rc;
+            if ((rc = fins())) return rc;
+            if ((rc = wgrad1())) return rc;
+            if (i > 0 && (rc = wgrad2(i - 1))) return rc;
+        } else if (!side_stream && (rc = wgrad1())) return rc;
     }
     if (chain.slab && (rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs
     // flags bit 0: leave the second stream un-joined (the caller issues more work behind it -- e.g. this bucket's gradient

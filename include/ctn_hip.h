@@ -188,7 +188,8 @@ int ctn_dw_fwd(const float* Y, float* Z, const float* D, int M, int H, int K, in
  *   out: dN1 (grad of gLN1's output), sums1_part [M,H,2] fp64 (S1,S2 for gLN1's backward) and
  *        pc [F, M, H] per-(utterance, channel) partials, F = ctn_dw_bwd_rows(P, fused):
  *        rows 0..P-1 dD taps; fused adds P: dgamma2, P+1: dbeta2, P+2: dgamma1, P+3: dbeta1, P+4: dalpha2.
- * fused = 0: dN2 = dZ, Y1 = the forward input; outputs dN1 = dY and pc rows 0..P-1. */
+ * fused = 0: dN2 = dZ, Y1 = the forward input; outputs dN1 = dY and pc rows 0..P-1.
+ * (fused = 2 is the channel-wise LayerNorm form behind ctn_dw_bwd_cln below: call that.) */
 int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, const float* D,
                int M, int H, int K, int Kp, int P, int dilation, int causal, int fused,
                const float* g1, const float* b1, const float* a1, const float* ms1,

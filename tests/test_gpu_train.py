@@ -423,6 +423,33 @@ def test_cln_composite_is_bitwise_the_per_kernel_path_at_every_fusion_level(leve
         ops._ws_cache.clear()
 
 
+@pytest.mark.parametrize("norm_type,causal", [("gLN", False), ("cLN", True)])
+def test_one_fork_per_block_backward_is_bitwise_the_two_fork_schedule(norm_type, causal):
+    """ctn_tune("bwd_events", 1): the composite backward forks the weight-gradient stream once per block (behind B5: dW1 and the sums
+    of that block, then dW2 of the NEXT block, which needs only that B5's output) instead of twice.  Only the queueing changes:
+    every gradient is bitwise the two-fork schedule's."""
+    from conv_tasnet_amd import ops
+    mix, lens, src = O.synth_batch(5, 3, 4000 + 7)
+    res = []
+    try:
+        for ev in (2, 1, 1):
+            ctn.lib.call("ctn_tune", b"bwd_events", ev)
+            torch.manual_seed(3)
+            m = ctn.ConvTasNet(64, 20, 64, 128, 3, 3, 2, 2, norm_type=norm_type, causal=causal).to(DEV)
+            opt = FlatAdam(m.parameters(), lr=1e-3)
+            opt.zero_grad()
+            loss = ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0]
+            loss.backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append([p.grad.detach().clone() for p in m.parameters()])
+    finally:
+        ctn.lib.call("ctn_tune", b"bwd_events", 2)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
 def test_evaluate_with_the_reference_signature(tmp_path, capsys):
     """evaluate(model_path, data_dir, calc_sdr, use_cuda, sample_rate, batch_size), src/evaluate.py:21: checkpoint file +
     {mix,s1,s2}.json manifests of wav files in, average SI-SNRi out; calc_sdr (mir_eval) is an explicit error."""
