@@ -13,6 +13,7 @@
 #include "ctn_common.h"
 #include "../../include/ctn_hip.h"
 #include <mutex>
+#include <stdlib.h>
 #include <vector>
 
 
@@ -72,8 +73,17 @@ int g_ctn_exp_skip = 0;
 // ctn_tune("bwd_events", 1 | 2): cross-stream events per block of the backward pass.  2 (rounds 1-4): the second 1x1 conv's weight
 // gradient is forked behind B1, the first one's behind B4.  1: ONE fork per block, behind B5 -- dW2 of block i needs only dy_i (the
 // output of B5 of block i+1) and forward tensors, so it rides behind the event that releases dW1 of block i+1; each event costs the
-// main chain ~5 us (profiles/README.md r04_k).
-int g_ctn_bwd_events = 2;
+// main chain ~5 us (profiles/README.md r04_k).  0 (default) = the measured best per stack: gLN 1 (paper step 10.19 -> 10.14 ms), cLN 2
+// (11.44 vs 11.79 ms with one fork: its second stream carries the latency-bound sums that the early dW2 then queues behind).
+// CTN_BWD_EVENTS=1|2 at first use overrides it (fresh-process A/B).
+int g_ctn_bwd_events = -1;
+static int bwd_events(int dflt) {
+    if (g_ctn_bwd_events < 0) {
+        const char* e = getenv("CTN_BWD_EVENTS");
+        g_ctn_bwd_events = (e && (*e == '1' || *e == '2')) ? *e - '0' : 0;
+    }
+    return g_ctn_bwd_events ? g_ctn_bwd_events : dflt;
+}
 
 namespace {
 
@@ -323,7 +333,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         }
         if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
     }
-    const bool one_event = side_stream != nullptr && g_ctn_bwd_events == 1;
+    const bool one_event = side_stream != nullptr && bwd_events(1) == 1;
     // the second 1x1 conv's weight gradient of block j: dW2 = dy_j . gLN2(prelu(d_j))^T -- it needs dy_j and forward tensors only
     auto wgrad2 = [&](int j) -> int {
         const float* const* pj = (const float* const*)(params + (size_t)j * NPARAM);
@@ -596,7 +606,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
         }
         if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
     }
-    const bool one_event = side_stream != nullptr && g_ctn_bwd_events == 1;       // (see ctn_tcn_gln_bwd)
+    const bool one_event = side_stream != nullptr && bwd_events(2) == 1;       // (see ctn_tcn_gln_bwd)
     auto wgrad2 = [&](int j) -> int {       // dW2 of block j = dy_j . n2_j^T: needs dy_j and forward tensors only
         float* const* gj = (float* const*)(grads + (size_t)j * NPARAM);
         const float* const n2j = n2s + (size_t)j * hsz;

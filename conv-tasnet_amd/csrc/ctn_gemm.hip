@@ -686,7 +686,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "cln_lean") && (value == 0 || value == 1)) g_ctn_cln_lean = value;
     else if (!strcmp(key, "cln_fuse") && value >= 0 && value <= 2) g_ctn_cln_fuse = value;
     else if (!strcmp(key, "exp_skip") && value >= 0) g_ctn_exp_skip = value;
-    else if (!strcmp(key, "bwd_events") && (value == 1 || value == 2)) g_ctn_bwd_events = value;
+    else if (!strcmp(key, "bwd_events") && value >= 0 && value <= 2) g_ctn_bwd_events = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
 }
