@@ -10,7 +10,8 @@ autograd node:
 
   Frontend : encoder conv + ReLU -> input cLN -> bottleneck 1x1   (src/conv_tasnet.py:108-121,172-174)
   GlnBlock : TemporalBlock with gLN, fully fused                  (src/conv_tasnet.py:218-278)
-  ClnBlock : TemporalBlock with cLN (causal variant)              (same, norm_type='cLN')
+  ClnBlock : TemporalBlock with cLN (causal variant)              (same, norm_type='cLN'; the first norm's forward and the second
+             norm's backward ride in the neighbouring GEMM epilogues / depthwise kernels: ctn_tune("cln_fuse"), include/ctn_hip.h)
   Backend  : mask 1x1 -> relu|softmax -> mask*w -> basis -> OLA   (src/conv_tasnet.py:191,206-215,131-146)
   SiSnrPit : PIT SI-SNR loss                                      (src/pit_criterion.py:12-77)
 """
