@@ -693,7 +693,7 @@ int ctn_tcn_cln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = ctn_stream_order(stream, side_stream))) return rc;
             if ((rc = fins())) return rc;
             if ((rc = wgrad1())) return rc;
-            if (i > 0 && (rc = wgrad2(i - 1))) return rc;
+            if (i > 0 && (rc = wgrad2(i - 1))) return rc;       // (ahead of the sums instead: 12.09 vs 11.97 ms; two forks: 11.60)
         } else if (!side_stream && (rc = wgrad1())) return rc;
     }
     if (chain.slab && (rc = PROBED(F_WFLUSH, wst, ctn_wgrad_chain_flush(&chain, wst)))) return rc;     // the last weight gradient's slabs

@@ -873,6 +873,7 @@ class TcnCln(torch.autograd.Function):
         ctx.acts = (x0, xs, hs, st, amax)
         ctx.save_for_backward(*params)      # (autograd's version check: an in-place parameter update before backward is an error)
         ctx.cfg = (K, dil, nb, causal, P)
+        ctx.fuse = lib.ctn_cln_fuse()       # what the forward pass stored (level 2: no n1) -- the backward pass must run under the same value
         ctx.sinks = tuple(_sink(p) for p in params)
         return xs[nb - 1]
 
@@ -882,6 +883,9 @@ class TcnCln(torch.autograd.Function):
             raise CtnError("composite TemporalBlock stack: backward called twice on one forward pass (its saved activations are "
                            "released after the first); set CTN_COMPOSITE=0 for retain_graph=True")
         x0, xs, hs, st, amax = ctx.acts
+        if (lib.ctn_cln_fuse() >= 2) != (ctx.fuse >= 2):
+            raise CtnError("ctn_tune(\"cln_fuse\") changed between the forward and the backward pass of a cLN stack (%d -> %d): the first "
+                           "norm's output is stored only below level 2" % (ctx.fuse, lib.ctn_cln_fuse()))
         params = ctx.saved_tensors
         K, dil, nb, causal, P = ctx.cfg
         dout = _c(dout)

@@ -450,6 +450,23 @@ def test_one_fork_per_block_backward_is_bitwise_the_two_fork_schedule(norm_type,
             assert torch.equal(a, b)
 
 
+def test_cln_fusion_level_must_not_change_between_forward_and_backward():
+    """Level 2 of ctn_tune("cln_fuse") never stores the first norm's output: a backward pass under a lower level would read a
+    buffer that was never written -- the composite stack refuses it."""
+    if ctn.lib.ctn_gemm_arith() != 3:
+        pytest.skip("one arithmetic is enough")
+    mix, lens, src = O.synth_batch(5, 2, 3000)
+    torch.manual_seed(3)
+    m = ctn.ConvTasNet(32, 20, 16, 32, 3, 2, 1, 2, norm_type="cLN", causal=True).to(DEV)
+    loss = ctn.cal_loss(src.to(DEV), m(mix.to(DEV)), lens.to(DEV))[0]
+    ctn.lib.call("ctn_tune", b"cln_fuse", 0)
+    try:
+        with pytest.raises(ctn.CtnError, match="cln_fuse"):
+            loss.backward()
+    finally:
+        ctn.lib.call("ctn_tune", b"cln_fuse", 2)
+
+
 def test_evaluate_with_the_reference_signature(tmp_path, capsys):
     """evaluate(model_path, data_dir, calc_sdr, use_cuda, sample_rate, batch_size), src/evaluate.py:21: checkpoint file +
     {mix,s1,s2}.json manifests of wav files in, average SI-SNRi out; calc_sdr (mir_eval) is an explicit error."""
