@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Package power of the paper-config training step under both GEMM arithmetics (see power_lab.py / power_lab.sh step)."""
+"""Package power of the paper-config training step under the three GEMM arithmetics (see power_lab.sh step); POWER_CONFIG=causal: the
+causal cLN config under h3 at the three fusion levels of its channel-wise norms (ctn_tune("cln_fuse", 0 | 1 | 2))."""
 import os
 import sys
 import time
@@ -12,7 +13,8 @@ from conv_tasnet_amd.train import SyntheticLoader  # noqa: E402
 
 dev = "cuda:0"
 SECONDS = float(os.environ.get("SECONDS_PER_CASE", "4"))
-m = ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2).to(dev)
+CAUSAL = os.environ.get("POWER_CONFIG", "paper") == "causal"
+m = (ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2, norm_type="cLN", causal=True) if CAUSAL else ctn.ConvTasNet(256, 20, 256, 512, 3, 8, 4, 2)).to(dev)
 opt = FlatAdam(m.parameters(), lr=1e-3)
 mix, lens, src = next(iter(SyntheticLoader(1, 8, samples=32000)))
 mix, lens, src = mix.to(dev), lens.to(dev), src.to(dev)
@@ -40,6 +42,13 @@ def case(name, fn):
 
 
 case("idle", lambda: time.sleep(0.01))
-for arith in ("h3", "b6", "fp32", "h3"):
-    ctn.set_gemm_arith(arith)
-    case("training_step_" + arith, step)
+if CAUSAL:
+    for level in (0, 1, 2, 0, 2):
+        ctn.lib.call("ctn_tune", b"cln_fuse", level)
+        ctn.ops._ws_cache.clear()
+        case("causal_step_h3_cln_fuse_%d" % level, step)
+    ctn.lib.call("ctn_tune", b"cln_fuse", 2)
+else:
+    for arith in ("h3", "b6", "fp32", "h3"):
+        ctn.set_gemm_arith(arith)
+        case("training_step_" + arith, step)
