@@ -68,8 +68,13 @@ extern "C" int ctn_probe_read(int* fam, float* us, int cap) {
     return n;
 }
 
-// lab switch, ctn_tune("exp_skip", mask): TIMING experiments only (results are wrong): bit 0 = the gLN stack's backward skips B4
+// lab builds only (-DCTN_EXP_SKIP; never in the product library): ctn_tune("exp_skip", mask) for TIMING experiments whose results are
+// wrong -- bit 0 = the gLN stack's backward skips B4 (profiles/README.md r04_j)
+#ifdef CTN_EXP_SKIP
 int g_ctn_exp_skip = 0;
+#else
+static constexpr int g_ctn_exp_skip = 0;
+#endif
 // ctn_tune("bwd_events", 1 | 2): cross-stream events per block of the backward pass.  2 (rounds 1-4): the second 1x1 conv's weight
 // gradient is forked behind B1, the first one's behind B4.  1: ONE fork per block, behind B5 -- dW2 of block i needs only dy_i (the
 // output of B5 of block i+1) and forward tensors, so it rides behind the event that releases dW1 of block i+1; each event costs the

@@ -430,7 +430,9 @@ __global__ __launch_bounds__(NT) void pw_wgrad4_kernel(WgArgs a) {
 int g_ctn_tile_override = -2;
 extern int g_ctn_cln_lean;
 extern int g_ctn_bwd_events;                // csrc/ctn_block.hip: cross-stream forks per block of the composite backward passes
-extern int g_ctn_exp_skip;                  // csrc/ctn_block.hip: timing-experiment switch
+#ifdef CTN_EXP_SKIP
+extern int g_ctn_exp_skip;                  // csrc/ctn_block.hip: timing-experiment switch of lab builds
+#endif
 extern int g_ctn_cln_fuse;                  // csrc/ctn_tcn.hip: cLN stacks with the second norm's backward fused into its neighbours
 extern int g_ctn_cln_fr;                    // csrc/ctn_tcn.hip: frames per workgroup of the channel-wise LayerNorm backward kernel
 
@@ -685,7 +687,9 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_chain") && (value == 0 || value == 1)) g_ctn_wgrad_chain = value;
     else if (!strcmp(key, "cln_lean") && (value == 0 || value == 1)) g_ctn_cln_lean = value;
     else if (!strcmp(key, "cln_fuse") && value >= 0 && value <= 2) g_ctn_cln_fuse = value;
+#ifdef CTN_EXP_SKIP
     else if (!strcmp(key, "exp_skip") && value >= 0) g_ctn_exp_skip = value;
+#endif
     else if (!strcmp(key, "bwd_events") && value >= 0 && value <= 2) g_ctn_bwd_events = value;
     else { ctn_set_error("ctn_tune: unknown key or bad value: %s=%d", key, value); return CTN_ERR_ARG; }
     return CTN_OK;
