@@ -253,6 +253,29 @@ def test_cln_forward_statistics_from_the_gemm_epilogue_against_fp64():
     assert float(mean[:, K:].abs().max()) == 0.0 and abs(float(rstd[0, K]) - 1e4) < 1.0
 
 
+def test_cln_fused_entry_points_reject_bad_arguments():
+    """Error behaviour of the round-4 entry points: an unknown weight form, h3 pieces without the operand's maximum, a missing
+    per-frame vector -- int status + message, nothing launched."""
+    from conv_tasnet_amd.ops import _p, _stream
+    M, R, Cn, K = 1, 64, 64, 100
+    Kp = ops.padded_frames(K)
+    z = lambda *sh: torch.zeros(*sh, device=DEV)  # noqa: E731
+    W, X, Out, al = z(R, Cn), z(M, Cn, Kp), z(M, R, Kp), z(1)
+    part = torch.zeros((M, 8, Kp, 2), dtype=torch.float64, device=DEV)
+    mean, rstd, gam = z(M, Kp), z(M, Kp), z(R)
+    dll = ctn.lib.load()
+    assert dll.ctn_pw_gemm_cln(_p(W), 7, _p(X), _p(Out), M, R, Cn, K, Kp, _p(al), _p(part), 0, _stream()) != 0
+    assert b"w_form" in dll.ctn_last_error()
+    assert dll.ctn_pw_gemm_cln(_p(W), 3, _p(X), _p(Out), M, R, Cn, K, Kp, _p(al), _p(part), 0, _stream()) != 0      # h3 pieces need x_amax
+    assert dll.ctn_pw_dgrad_cln(_p(W), 1, _p(X), _p(Out), M, R, Cn, K, Kp, _p(Out), _p(gam), _p(al), 0, _p(rstd), _p(part), 0, _stream()) != 0
+    assert b"null" in dll.ctn_last_error()
+    assert dll.ctn_cln_stats_frame(_p(part), 0, _p(mean), _p(rstd), M, R, Kp, _stream()) != 0
+    assert dll.ctn_dw_bwd_cln(_p(Out), _p(Out), _p(Out), _p(Out), _p(z(R, 3)), M, R, K, Kp, 3, 1, 1, _p(gam), _p(al), _p(z(M, 4, Kp)),
+                              _p(gam), 0, 0, 0, 0, _p(z(6, M, R)), _stream()) != 0          # first-norm arguments come together
+    with pytest.raises(ctn.CtnError):
+        ctn.lib.call("ctn_tune", b"cln_fuse", 5)
+
+
 def test_cln_backward_entry_points_against_fp64():
     """ctn_pw_dgrad_cln + ctn_cln_bwd_frame against fp64 torch: dN, and fc = (rstd, mean rstd, rstd S1/Ch, rstd S2/Ch) per frame."""
     M, R, Cn, K = 2, 192, 64, 333
