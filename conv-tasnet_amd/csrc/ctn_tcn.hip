@@ -1469,9 +1469,15 @@ int ctn_gln_bwd_sums(const float* dN, const float* Y, int M, int H, int K, int K
 // (512 threads); ctn_tune("cln_fr", 16 | 32).  The backward partial buffers are sized and summed by this count for every kernel
 // of the family.
 int g_ctn_cln_fr = 16;
-int g_ctn_cln_fuse = 2;          // ctn_tune("cln_fuse", 0 | 1 | 2): 1 = composite cLN stacks run the second norm's backward inside the input-gradient
+int g_ctn_cln_fuse = -1;         // ctn_tune("cln_fuse", 0 | 1 | 2): 1 = composite cLN stacks run the second norm's backward inside the input-gradient
                                  // GEMM's epilogue (per-frame sums) and the depthwise backward's dd image instead of as a pass of its own
-int ctn_cln_fuse(void) { return g_ctn_cln_fuse; }
+int ctn_cln_fuse(void) {         // (-1: not read yet; CTN_CLN_FUSE=0|1|2 at first use, for fresh-process A/B runs; default 2)
+    if (g_ctn_cln_fuse < 0) {
+        const char* e = getenv("CTN_CLN_FUSE");
+        g_ctn_cln_fuse = (e && *e >= '0' && *e <= '2' && !e[1]) ? *e - '0' : 2;
+    }
+    return g_ctn_cln_fuse;
+}
 int g_ctn_cln_lean = 1;          // ctn_tune("cln_lean", 0 | 1): the specialised backward kernel for the stacks' form
 
 static bool cln_v4_ok(int Ch, int Kp, const void* a, const void* b, const void* c) {

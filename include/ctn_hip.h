@@ -96,7 +96,8 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * composite cLN stacks run the second norm's backward inside the input-gradient GEMM's epilogue and the depthwise backward
  * (ctn_pw_dgrad_cln / ctn_cln_bwd_frame / ctn_dw_bwd_cln) instead of as a ctn_cln_bwd pass; 2 = also the first norm's forward
  * inside the first 1x1 conv's epilogue and the depthwise kernel's prologue (ctn_pw_gemm_cln / ctn_cln_stats_frame / ctn_dw_fwd_cln:
- * n1s is then neither written nor read; set it between steps, forward and backward under the same value); ctn_cln_fuse() reads it;
+ * n1s is then neither written nor read; set it between steps, forward and backward under the same value; CTN_CLN_FUSE=0|1|2 at first
+ * use); ctn_cln_fuse() reads it;
  * "bwd_events" 0|1|2 (default 0 = gLN stacks 1, cLN stacks 2; CTN_BWD_EVENTS=1|2 at first use): forks of the weight-gradient stream
  * per block of the composite backward passes -- 2: dW2 behind B1 and dW1 behind the norm backward; 1: one fork behind B5 (dW1 and the
  * sums of that block, then dW2 of the next block, which needs only that B5's output); same gradients bit for bit.  Defaults are the
