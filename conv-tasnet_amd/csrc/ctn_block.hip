@@ -182,11 +182,11 @@ BwdWs bwd_ws(int M, int B, int H, int Kp, int P, int nblocks) {
     w.np2 = ctn_pw_stats_parts(M, H, Kp);
     size_t o = 0;
     w.dn2 = o; o += align256((size_t)M * H * Kp * sizeof(float));
-    w.s2p = o; o += align256((size_t)M * w.np2 * 2 * sizeof(double));
+    w.s2p = o; o += align256((size_t)M * w.np2 * 8 * sizeof(double));        // (8 sums per tile with ctn_tune("gln_fuse", 1), else 2)
     w.s1p_slot = align256((size_t)M * H * 2 * sizeof(double));        // per block: the fused weight gradient of the second stream reads it
     w.s1p = o; o += (size_t)nblocks * w.s1p_slot;
     // per-block slots: the finalize kernel of block i runs on the weight-gradient stream while the chain is already in block i-1
-    w.pc_slot = align256((size_t)ctn_dw_bwd_rows(P, 1) * M * H * sizeof(float));
+    w.pc_slot = align256((size_t)ctn_dw_bwd_rows(P, 3) * M * H * sizeof(float));      // (a row more than fused = 1: the dalpha1 partials of gln_fuse)
     w.da1p_slot = align256((size_t)M * H * sizeof(float));          // PReLU-slope partials of ctn_gln_prelu_bwd: one per (m, channel)
     w.pc = o; o += (size_t)nblocks * w.pc_slot;
     w.da1p = o; o += (size_t)nblocks * w.da1p_slot;
@@ -338,6 +338,7 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         }
         if ((rc = PROBED(F_PREP, stream, ctn_absmax_rows(dout, M, (long long)B * Kp, amax_b + (size_t)(2 * (nblocks - 1)) * M * CTN_AMAX_SLOTS, stream)))) return rc;
     }
+    const bool fuse4 = ctn_gln_fuse() != 0;       // no gLN-1' / PReLU-1' pass: its sums come out of B1's epilogue, B3 applies it
     const bool one_event = side_stream != nullptr && bwd_events(1) == 1;
     // the second 1x1 conv's weight gradient of block j: dW2 = dy_j . gLN2(prelu(d_j))^T -- it needs dy_j and forward tensors only
     auto wgrad2 = [&](int j) -> int {
@@ -374,7 +375,9 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
         float* const da1p = (float*)(ws + w.da1p + (size_t)i * w.da1p_slot);
         double* const s1p = (double*)(ws + w.s1p + (size_t)i * w.s1p_slot);
         // second 1x1: input gradient (+ gLN2 backward sums); its weight gradient on the side stream
-        if (h3) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_h3(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, ady, stream));
+        if (fuse4) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln2(twh == -1 ? (const void*)p[P_W2] : (const void*)(wreg + (size_t)(2 * i) * slot), h3 ? 3 : (twh == 2 ? 2 : 1),
+                               dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, p[P_G1], p[P_B1], p[P_D], P, dilation[i], causal, s2p, h3 ? ady : nullptr, stream));
+        else if (h3) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_h3(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, ady, stream));
         else if (twh == 2) rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln_planes(wreg + (size_t)(2 * i) * slot, dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         else rc = PROBED(F_B1, stream, ctn_pw_dgrad_gln(p[P_W2], dy, dn2, M, H, B, K, Kp, d, p[P_G2], p[P_A2], ms2, s2p, stream));
         if (rc) return rc;
@@ -383,13 +386,16 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             if ((rc = wgrad2(i))) return rc;
         }
         // gLN2 <- PReLU2 <- depthwise <- gLN1 output in one pass, then gLN1 + PReLU1 backward in place
-        rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
+        if (fuse4) rc = PROBED(F_B3, stream, ctn_dw_bwd_gln2(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, p[P_G1], p[P_B1], p[P_A1], ms1,
+                               p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, h3 ? adh : nullptr, stream));       // (dn1 receives dh1)
+        else rc = PROBED(F_B3, stream, ctn_dw_bwd(dn2, d, h1, dn1, p[P_D], M, H, K, Kp, P, dilation[i], causal, 1, p[P_G1], p[P_B1], p[P_A1], ms1,
                         p[P_G2], p[P_A2], ms2, s2p, w.np2, pc, s1p, stream));
         if (rc) return rc;
         // gLN1' / PReLU1' backward in place (B4).  (Folding it into the operand prologues of its two consumers was built and
         // measured in round 2: 10.23 vs 10.13 ms per step with B4 as its own pass -- both GEMMs then read h1 as well.)
         const int n_da1 = M * H;
-        if (!(g_ctn_exp_skip & 1)) rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, h3 ? adh : nullptr, stream));
+        if (fuse4) rc = CTN_OK;
+        else if (!(g_ctn_exp_skip & 1)) rc = PROBED(F_B4, stream, ctn_gln_prelu_bwd(dn1, h1, dn1, M, H, K, Kp, p[P_G1], p[P_A1], ms1, s1p, H, da1p, h3 ? adh : nullptr, stream));
         else if (h3) rc = ctn_absmax_rows(dn1, M, (long long)H * Kp, adh, stream);        // (lab: keep the h3 scales finite)
         if (rc) return rc;
         // first 1x1; the weight gradient and the fixed-order sums of this block's parameter-gradient partials feed only the
@@ -400,7 +406,8 @@ int ctn_tcn_gln_bwd(const void* const* params, void* const* grads, const int* di
             return PROBED(F_B6, wst, ctn_pw_wgrad_chained(dn1, x, g[P_W1], M, H, B, K, Kp, nullptr, nullptr, nullptr, nullptr, slabs[nwg++ & 1], w.slab_bytes, wst, &chain));
         };
         auto finalize = [&](void* st) -> int {
-            return PROBED(F_FIN, st, ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2], da1p, n_da1, g[P_A1], st));
+            return PROBED(F_FIN, st, ctn_dw_bwd_finalize(pc, P, M, H, g[P_D], g[P_G2], g[P_B2], g[P_G1], g[P_B1], g[P_A2],
+                                                        fuse4 ? pc + (size_t)(P + 5) * M * H : da1p, n_da1, g[P_A1], st));
         };
         if (side_stream && !one_event) {          // the fixed-order sums feed only the optimiser: second stream, behind the weight gradient
             if ((rc = wgrad1())) return rc;

@@ -433,6 +433,7 @@ extern int g_ctn_bwd_events;                // csrc/ctn_block.hip: cross-stream 
 #ifdef CTN_EXP_SKIP
 extern int g_ctn_exp_skip;                  // csrc/ctn_block.hip: timing-experiment switch of lab builds
 #endif
+extern int g_ctn_gln_fuse;                  // csrc/ctn_tcn.hip: gLN stacks without the gLN-1' / PReLU-1' pass
 extern int g_ctn_cln_fuse;                  // csrc/ctn_tcn.hip: cLN stacks with the second norm's backward fused into its neighbours
 extern int g_ctn_cln_fr;                    // csrc/ctn_tcn.hip: frames per workgroup of the channel-wise LayerNorm backward kernel
 
@@ -467,7 +468,8 @@ template <typename TL>
 static void launch_tile(const PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd,
                         hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
+    if (gln_bwd == 3) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD2>), grid, block, 0, st, a);
+    else if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
     else if (gln_bwd) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
         if (pro && residual) hipLaunchKernelGGL((pw_gemm_kernel<TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
@@ -687,6 +689,7 @@ int ctn_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_chain") && (value == 0 || value == 1)) g_ctn_wgrad_chain = value;
     else if (!strcmp(key, "cln_lean") && (value == 0 || value == 1)) g_ctn_cln_lean = value;
     else if (!strcmp(key, "cln_fuse") && value >= 0 && value <= 2) g_ctn_cln_fuse = value;
+    else if (!strcmp(key, "gln_fuse") && (value == 0 || value == 1)) g_ctn_gln_fuse = value;
 #ifdef CTN_EXP_SKIP
     else if (!strcmp(key, "exp_skip") && value >= 0) g_ctn_exp_skip = value;
 #endif
@@ -892,6 +895,38 @@ int ctn_pw_dgrad_cln(const void* W, int w_form, const float* dOut, float* dN, in
     else if (col_b3(R, w_form)) ctn_b3_launch_fwd(arith_np(), a, w_form == 2 ? 2 : 1, false, false, false, false, 2, (hipStream_t)stream);
     else launch_fwd(a, 1, false, false, false, false, 2, (hipStream_t)stream);
     CTN_CHECK_LAUNCH("ctn_pw_dgrad_cln");
+    return CTN_OK;
+}
+
+// gLN blocks without the gLN-1' / PReLU-1' pass (round 4; include/ctn_hip.h): ctn_pw_dgrad_gln plus six more per-utterance sums from which
+// the FIRST norm's backward sums follow before the depthwise backward has run -- the depthwise conv's adjoint moves them onto dd:
+//   S1' = sum gamma1 dn1      = sum_{c,k} dd[c,k] gamma1[c] V[c,k]
+//   S2' = sum gamma1 dn1 xh1  = sum_{c,k} dd[c,k] (d[c,k] - beta1[c] V[c,k]),     V[c,k] = sum of the taps of frame k that stay inside [0, K)
+// and dd = u rstd2 (t - c1 - xh2 c2) is affine in (c1, c2) = (S1, S2) / n, so with u = prelu'(d), t = gamma2 dN:
+//   sums_part [M, parts, 8] = S1, S2, sum u t g1V, sum u g1V, sum u xh2 g1V, sum u t e, sum u e, sum u xh2 e     (g1V = gamma1 V, e = d - beta1 V).
+// w_form as ctn_pw_dgrad_cln.
+int ctn_pw_dgrad_gln2(const void* W, int w_form, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                      const float* y, const float* gamma, const float* alpha, const float* ms,
+                      const float* gamma1, const float* beta1, const float* D, int P, int dilation, int causal,
+                      double* sums_part, const unsigned* g_amax, void* stream) {
+    int rc = check_common("ctn_pw_dgrad_gln2", (const float*)W, dOut, dN, M, R, Cn, K, Kp);
+    if (rc) return rc;
+    CTN_REQUIRE(w_form >= 1 && w_form <= 3, "ctn_pw_dgrad_gln2: w_form must be 1 (fp32 [Cn, R]), 2 (b6 pieces) or 3 (h3 pieces)");
+    CTN_REQUIRE(y && gamma && alpha && ms && gamma1 && beta1 && D && sums_part, "ctn_pw_dgrad_gln2: null pointer");
+    CTN_REQUIRE(aligned16(y) && P >= 1 && P <= 8 && dilation >= 1, "ctn_pw_dgrad_gln2: y must be 16-byte aligned, 1 <= P <= 8");
+    CTN_REQUIRE(w_form != 3 || (g_amax && R >= 64), "ctn_pw_dgrad_gln2: h3 pieces need the operand's maximum and R >= 64");
+    CTN_REQUIRE(w_form != 2 || b3_fwd(R), "ctn_pw_dgrad_gln2: b6 pieces need a split-bf16 arithmetic and R >= 64");
+    const int halo = (P - 1) * dilation;
+    CTN_REQUIRE(causal || halo % 2 == 0, "ctn_pw_dgrad_gln2: non-causal 'same' padding needs (P-1)*dilation even");
+    PwArgs a{};
+    a.W = (const float*)W; a.X = dOut; a.Out = dN; a.M = M; a.R = R; a.Cn = Cn; a.K = K; a.Kp = Kp;
+    a.bwd_y = y; a.bwd_gamma = gamma; a.bwd_alpha = alpha; a.bwd_ms = ms; a.bwd_part = sums_part;
+    a.g1 = gamma1; a.b1 = beta1; a.dw_D = D; a.dw_P = P; a.dw_dil = dilation; a.dw_padl = causal ? halo : halo / 2;
+    a.x_amax = g_amax;
+    if (w_form == 3) ctn_b3_launch_fwd(4, a, 2, false, false, false, false, 3, (hipStream_t)stream);
+    else if (col_b3(R, w_form)) ctn_b3_launch_fwd(arith_np(), a, w_form == 2 ? 2 : 1, false, false, false, false, 3, (hipStream_t)stream);
+    else launch_fwd(a, 1, false, false, false, false, 3, (hipStream_t)stream);
+    CTN_CHECK_LAUNCH("ctn_pw_dgrad_gln2");
     return CTN_OK;
 }
 

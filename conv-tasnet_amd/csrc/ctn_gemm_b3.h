@@ -920,9 +920,10 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
 }
 
 template <int AR, typename TL>
-void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {      // gln_bwd: 1 = EPI_GLN_BWD, 2 = EPI_CLN_BWD; stats: 1 = EPI_PRELU_STATS, 2 = EPI_CLN_STATS
+void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {      // gln_bwd: 1 = EPI_GLN_BWD, 2 = EPI_CLN_BWD, 3 = EPI_GLN_BWD2; stats: 1 = EPI_PRELU_STATS, 2 = EPI_CLN_STATS
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
+    if (gln_bwd == 3) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_GLN_BWD2>), grid, block, 0, st, a);
+    else if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
     else if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);
     else if (pro) hipLaunchKernelGGL((pw_gemm_b3p_kernel<AR, TL, PRO_PRELU_NORM, EPI_NONE>), grid, block, 0, st, a);
@@ -936,7 +937,8 @@ void launch_b3p_tile(const PwArgs& a, bool pro, bool residual, int stats, bool r
 template <int AR, typename TL>
 void launch_b3_tile(const PwArgs& a, int trans_w, bool pro, bool residual, int stats, bool relu, int gln_bwd, hipStream_t st) {
     const dim3 grid((unsigned)((long long)a.tiles_r * a.tiles_c * a.M)), block(TL::NTH);
-    if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
+    if (gln_bwd == 3) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_GLN_BWD2>), grid, block, 0, st, a);
+    else if (gln_bwd == 2) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_CLN_BWD>), grid, block, 0, st, a);
     else if (gln_bwd) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_NONE, EPI_GLN_BWD>), grid, block, 0, st, a);
     else if (trans_w) {
         if (pro && residual) hipLaunchKernelGGL((pw_gemm_b3_kernel<AR, TL, 1, PRO_PRELU_NORM, EPI_RESIDUAL>), grid, block, 0, st, a);

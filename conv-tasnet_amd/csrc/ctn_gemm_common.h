@@ -14,7 +14,7 @@ constexpr int NT = 256;
 constexpr int BM = 128, BN = 128;     // weight-gradient tile (below)
 
 enum { PRO_NONE = 0, PRO_PRELU_NORM = 1 };
-enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4, EPI_CLN_BWD = 5, EPI_CLN_STATS = 6 };
+enum { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_PRELU_STATS = 2, EPI_GLN_BWD = 3, EPI_RELU = 4, EPI_CLN_BWD = 5, EPI_CLN_STATS = 6, EPI_GLN_BWD2 = 7 };
 
 // Output tile BMxBN per 256-thread workgroup, waves arranged WGM x WGN, each wave (BM/WGM)x(BN/WGN)
 // in 32x32 MFMA tiles.  Smaller tiles trade operand reuse (plentiful: one fp32 MFMA = 64 cycles for one
@@ -64,6 +64,10 @@ struct PwArgs {
     // the norm's saved per-frame statistics, and the per-row-tile column partials col_part [M][tiles_r][Kp][2] =
     // (sum_c gamma_c dN[c,k], sum_c gamma_c dN[c,k] xhat[c,k]) over the tile's rows (summed over tiles_r by ctn_cln_bwd_frame)
     const float* cln_mean; const float* cln_rstd; double* col_part;
+    // EPI_GLN_BWD2 (round 4): EPI_GLN_BWD plus the six sums from which the FIRST norm's backward sums follow by adjointness of the
+    // depthwise conv (ctn_pw_dgrad_gln2, include/ctn_hip.h): bwd_part is [M, tiles, 8]; gamma / beta of the first norm, the depthwise
+    // taps D [R, dw_P] and its geometry
+    const float* g1; const float* b1; const float* dw_D; int dw_P, dw_dil, dw_padl;
     // EPI_CLN_STATS (channel-wise LayerNorm forward statistics from the producing GEMM): epi_alpha, and col_part receives
     // (sum_c p, sum_c p^2), p = prelu(Out[c,k], alpha), over the tile's rows (ctn_cln_stats_frame turns them into mean / rstd)
     // h3 arithmetic (ctn_gemm_b3.h): range information of the operands, all optional elsewhere
@@ -126,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     const int r0 = rt * TM, c0 = ct * TN;
     float e_alpha = 0.f, b_mean = 0.f, b_rstd = 1.f;
     if constexpr (EPI == EPI_PRELU_STATS) e_alpha = a.epi_alpha[0];
-    if constexpr (EPI == EPI_GLN_BWD) {
+    if constexpr (EPI == EPI_GLN_BWD || EPI == EPI_GLN_BWD2) {
         e_alpha = a.bwd_alpha[0];
         b_mean = a.bwd_ms[2 * m];
         b_rstd = a.bwd_ms[2 * m + 1];
@@ -143,9 +147,20 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     const __amdgpu_buffer_rsrc_t rsOut = make_rsrc(a.Out + mbase, mat_bytes);
     __amdgpu_buffer_rsrc_t rsAux = rsOut, rsGam = rsOut;
     if constexpr (EPI == EPI_RESIDUAL) rsAux = make_rsrc(a.residual + mbase, mat_bytes);
-    if constexpr (EPI == EPI_GLN_BWD || EPI == EPI_CLN_BWD) {
+    if constexpr (EPI == EPI_GLN_BWD || EPI == EPI_CLN_BWD || EPI == EPI_GLN_BWD2) {
         rsAux = make_rsrc(a.bwd_y + mbase, mat_bytes);
         rsGam = make_rsrc(a.bwd_gamma, (unsigned)a.R * 4u);
+    }
+    // EPI_GLN_BWD2: per-row constants of the first norm and the depthwise taps through range-checked descriptors (rows >= R read 0)
+    __amdgpu_buffer_rsrc_t rsG1 = rsOut, rsB1 = rsOut, rsD = rsOut;
+    float q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f, q8 = 0.f;
+    bool interior = false;
+    if constexpr (EPI == EPI_GLN_BWD2) {
+        rsG1 = make_rsrc(a.g1, (unsigned)a.R * 4u);
+        rsB1 = make_rsrc(a.b1, (unsigned)a.R * 4u);
+        rsD = make_rsrc(a.dw_D, (unsigned)a.R * (unsigned)a.dw_P * 4u);
+        // every tap of every frame of this tile inside [0, K): V = sum of the taps (uniform over the workgroup)
+        interior = c0 - a.dw_padl >= 0 && c0 + TN - 1 + (a.dw_P - 1) * a.dw_dil - a.dw_padl < a.K;
     }
     const bool ragged = c0 + TN > a.Kp;     // uniform
     const int rl0 = lane / C4, cl = (lane % C4) * 4;
@@ -203,6 +218,42 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                     const float x2 = (prelu_f(y.z, e_alpha) - b_mean) * b_rstd, x3 = (prelu_f(y.w, e_alpha) - b_mean) * b_rstd;
                     s1 += (t0 + t1) + (t2 + t3);
                     s2 += (t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3);
+                }
+                if constexpr (EPI == EPI_GLN_BWD2) {
+                    const float4 y = buf_ld4(rsAux, vo0, so);
+                    const int rrow = r0 + wm * WM + rl0, rso = mt * 32 + p * RPP;          // row = rrow + rso
+                    const float g = buf_ld1(rsGam, rrow * 4, rso * 4);
+                    const float g1v = buf_ld1(rsG1, rrow * 4, rso * 4), b1v = buf_ld1(rsB1, rrow * 4, rso * 4);
+                    float tap[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tap[j] = j < a.dw_P ? buf_ld1(rsD, (rrow * a.dw_P + j) * 4, rso * a.dw_P * 4) : 0.f;
+                    const float vv[4] = {v.x, v.y, v.z, v.w}, yy[4] = {y.x, y.y, y.z, y.w};
+                    float Vs = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Vs += tap[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float V = Vs;
+                        if (!interior) {
+                            V = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int kk = kcol + e + j * a.dw_dil - a.dw_padl;
+                                if (j < a.dw_P && kk >= 0 && kk < a.K) V += tap[j];
+                            }
+                        }
+                        const float t = g * vv[e];
+                        const float xh = (prelu_f(yy[e], e_alpha) - b_mean) * b_rstd;
+                        s1 += t;
+                        s2 += t * xh;
+                        if (kcol + e < a.K) {           // (frames >= K: t = 0, but the terms without t are not)
+                            const float u = yy[e] >= 0.f ? 1.f : e_alpha;
+                            const float w1 = g1v * V, w2 = yy[e] - b1v * V;
+                            const float ut = u * t, ux = u * xh;
+                            q3 += ut * w1; q4 += u * w1; q5 += ux * w1;
+                            q6 += ut * w2; q7 += u * w2; q8 += ux * w2;
+                        }
+                    }
                 }
                 if constexpr (EPI == EPI_CLN_BWD) {
                     // (rows >= R: gamma reads 0 through the range check and y reads 0: both sums get exact zeros)
@@ -265,6 +316,16 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
             double* const dst = a.col_part + (((size_t)m * a.tiles_r + rt) * a.Kp + c0 + tid) * 2;
             dst[0] = q1;
             dst[1] = q2;
+        }
+    }
+    if constexpr (EPI == EPI_GLN_BWD2) {
+        // (rows >= R: gamma2 and gamma1 read 0 and y reads 0 -> t = 0, w1 = 0, w2 = -b1 V = 0 as beta1 reads 0 too: exact zeros)
+        const float qs[8] = {s1, s2, q3, q4, q5, q6, q7, q8};
+        double* const dst = a.bwd_part + ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double di = block_sum<double, TL::NTH>((double)qs[i], red);
+            if (tid == 0) dst[i] = di;
         }
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {

@@ -188,7 +188,10 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(DwFwdArgs a) {
 //            xh2 = prelu(d) fc0 - fc1 ; da2 = g2 fc0 dN2 - fc2 - xh2 fc3 ; dd = da2 * prelu'(d)
 //          i.e. the whole stand-alone cLN-backward pass of the second norm (three tensor passes) rides in this kernel's dd image.
 // Template: DDM = how dd is formed (0 plain, 1 gLN, 2 cLN), XM = how the x image is formed (0 as stored, 1 gLN-1 recomputed from h1,
-// 2 cLN-1 recomputed from h1 with its per-frame statistics: the first norm's output is never stored).
+// 2 cLN-1 recomputed from h1 with its per-frame statistics: the first norm's output is never stored; 3 (with DDM = 1, round 4) as 1 AND
+// the first norm's own backward applied to the result: the kernel writes dh1 = gLN1' . PReLU1'(dn1) instead of dn1 -- its two sums
+// S1', S2' are known BEFORE this kernel runs (ctn_pw_dgrad_gln2: sums2_part is [M, parts, 8]), so the gln_prelu_bwd pass is gone;
+// pc gets a row P+5 with the dalpha1 partials).
 // per-row float outputs pc[f][m][c]:  f = 0..P-1: dD ; (DDM, XM) = (1, 1) adds P: dgamma2, P+1: dbeta2,
 //   P+2: dgamma1, P+3: dbeta1, P+4: dalpha2 ; (2, 0) adds P: dgamma2, P+1: dbeta2, P+2: dalpha2
 // ---------------------------------------------------------------------------
@@ -202,11 +205,13 @@ struct DwBwdArgs {
     double* sums1_part;    // [M, H, 2]
     const float* fc2;      // DDM = 2: [M][4][Kp] per-frame constants of the second norm's backward
     const float* mean1f; const float* rstd1f;      // XM = 2: [M][Kp] per-frame statistics of the first (channel-wise) norm
+    unsigned* amax_out;    // XM = 3: [M][CTN_AMAX_SLOTS] max |dY1[m]| (h3 arithmetic of the GEMMs that read it), optional
 };
 
 template <int DDM, int XM, int BWD_BUF, bool VEC4, int PT>
 __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
-    static_assert((DDM == 0 && XM == 0) || (DDM == 1 && XM == 1) || (DDM == 2 && (XM == 0 || XM == 2)), "supported forms");
+    static_assert((DDM == 0 && XM == 0) || (DDM == 1 && (XM == 1 || XM == 3)) || (DDM == 2 && (XM == 0 || XM == 2)), "supported forms");
+    constexpr bool APPLY = XM == 3;         // write dh1 (first norm's backward applied) instead of dn1
     constexpr bool FUSED = DDM == 1;        // (the gLN form couples both images)
     constexpr bool XHAT = XM != 0;          // the x image holds xhat1: gamma1 / beta1 are applied where it is read
     __shared__ __attribute__((aligned(16))) float bufA[ROWS][BWD_BUF];  // dd
@@ -228,17 +233,26 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
 
     float mean1 = 0.f, rstd1 = 1.f, mean2 = 0.f, rstd2 = 1.f, al1 = 0.f, al2 = 0.f;
     float g1 = 1.f, b1 = 0.f, g2 = 1.f, c1 = 0.f, c2 = 0.f;
+    float c1p = 0.f, c2p = 0.f;            // APPLY: S1' / n, S2' / n of the first norm
     if constexpr (FUSED) {
-        double S1 = 0.0, S2 = 0.0;
-        for (int i = tid; i < a.sums2_nparts; i += NT) {
-            S1 += a.sums2_part[((size_t)m * a.sums2_nparts + i) * 2];
-            S2 += a.sums2_part[((size_t)m * a.sums2_nparts + i) * 2 + 1];
-        }
-        S1 = block_sum<double, NT>(S1, red);
-        S2 = block_sum<double, NT>(S2, red);
+        constexpr int NS = APPLY ? 8 : 2;
+        double S[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) S[q] = 0.0;
+        for (int i = tid; i < a.sums2_nparts; i += NT)
+#pragma unroll
+            for (int q = 0; q < NS; ++q) S[q] += a.sums2_part[((size_t)m * a.sums2_nparts + i) * NS + q];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) S[q] = block_sum<double, NT>(S[q], red);
         const double n = (double)a.H * (double)a.K;
-        c1 = (float)(S1 / n);
-        c2 = (float)(S2 / n);
+        const double d1 = S[0] / n, d2 = S[1] / n;
+        c1 = (float)d1;
+        c2 = (float)d2;
+        if constexpr (APPLY) {          // S1' = rstd2 (A1 - c1 B1 - c2 C1), S2' = rstd2 (A2 - c1 B2 - c2 C2)   (ctn_pw_dgrad_gln2)
+            const double r2 = (double)a.ms2[2 * m + 1];
+            c1p = (float)(r2 * (S[2] - d1 * S[3] - d2 * S[4]) / n);
+            c2p = (float)(r2 * (S[5] - d1 * S[6] - d2 * S[7]) / n);
+        }
         mean1 = a.ms1[2 * m]; rstd1 = a.ms1[2 * m + 1];
         mean2 = a.ms2[2 * m]; rstd2 = a.ms2[2 * m + 1];
         al1 = a.a1[0]; al2 = a.a2[0];
@@ -268,6 +282,16 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) dD[j] = 0.f;
     float dg2 = 0.f, db2 = 0.f, dal2 = 0.f, dg1 = 0.f, db1 = 0.f, t1 = 0.f, t2 = 0.f;
+    float dal1 = 0.f, amax1 = 0.f;
+    const float rg1 = rstd1 * g1, rc1p = rstd1 * c1p, rc2p = rstd1 * c2p;       // APPLY: da1 = rstd1 (g1 dn1 - c1' - xh1 c2')
+    // dh1 of one element: dn = dn1[k], xh = xhat1[k], h = h1[k] (its sign selects the PReLU branch); k < K
+    auto apply1 = [&](float dn, float xh, float h) -> float {
+        const float da = fmaf(-xh, rc2p, fmaf(rg1, dn, -rc1p));
+        if (h < 0.f) dal1 += da * h;
+        const float o = h >= 0.f ? da : al1 * da;
+        amax1 = fmaxf(amax1, fabsf(o));
+        return o;
+    };
 
     for (int k0 = 0; k0 < a.Kp; k0 += a.seg) {
         const int kend = min(k0 + a.seg, a.Kp);
@@ -388,14 +412,20 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                 if constexpr (FUSED) {
                     const float4 hq = *reinterpret_cast<const float4*>(LB + (k - baseB));
                     const float xh[4] = {hq.x, hq.y, hq.z, hq.w};
+                    float4 hr = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (APPLY) { if (live) hr = ld4(y1 + k); }       // (the raw h1: its sign; the lines were just read for the image)
+                    const float hv[4] = {hr.x, hr.y, hr.z, hr.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (k + e < a.K) {
                             dg1 += accv[e] * xh[e];
                             db1 += accv[e];
-                            const float t = g1 * accv[e];
-                            t1 += t;
-                            t2 += t * xh[e];
+                            if constexpr (APPLY) accv[e] = apply1(accv[e], xh[e], hv[e]);
+                            else {
+                                const float t = g1 * accv[e];
+                                t1 += t;
+                                t2 += t * xh[e];
+                            }
                         }
                 }
                 if (live) *reinterpret_cast<float4*>(dn1 + k) = make_float4(accv[0], accv[1], accv[2], accv[3]);
@@ -419,9 +449,12 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                     const float xh1 = LB[k - baseB];
                     dg1 += acc * xh1;
                     db1 += acc;
-                    const float t = g1 * acc;
-                    t1 += t;
-                    t2 += t * xh1;
+                    if constexpr (APPLY) acc = apply1(acc, xh1, live ? y1[k] : 0.f);
+                    else {
+                        const float t = g1 * acc;
+                        t1 += t;
+                        t2 += t * xh1;
+                    }
                 }
                 if (live) dn1[k] = acc;
                 continue;
@@ -450,9 +483,12 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
                     const float xh1 = LB[k - baseB];
                     dg1 += acc * xh1;
                     db1 += acc;
-                    const float t = g1 * acc;
-                    t1 += t;
-                    t2 += t * xh1;
+                    if constexpr (APPLY) acc = apply1(acc, xh1, live ? y1[k] : 0.f);
+                    else {
+                        const float t = g1 * acc;
+                        t1 += t;
+                        t2 += t * xh1;
+                    }
                 }
             }
             if (live) dn1[k] = acc;
@@ -484,8 +520,15 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
             a.pc[(size_t)(P_ + 2) * MH + rc] = v2;
             a.pc[(size_t)(P_ + 3) * MH + rc] = v3;
             a.pc[(size_t)(P_ + 4) * MH + rc] = v4;
-            a.sums1_part[rc * 2] = w1;
-            a.sums1_part[rc * 2 + 1] = w2;
+            if constexpr (!APPLY) {
+                a.sums1_part[rc * 2] = w1;
+                a.sums1_part[rc * 2 + 1] = w2;
+            }
+        }
+        if constexpr (APPLY) {
+            const float v5 = wave_sum(dal1);
+            if (live && lane == 0) a.pc[(size_t)(P_ + 5) * MH + rc] = v5;
+            if (a.amax_out != nullptr) block_amax_atomic<NT>(amax1, red, a.amax_out + (size_t)m * CTN_AMAX_SLOTS, blockIdx.x % hb);
         }
     }
 }
@@ -1315,7 +1358,8 @@ static int dw_fwd_launch(const DwFwdArgs& a, int pro, bool epi, bool small, void
 
 extern "C" {
 
-int ctn_dw_bwd_rows(int P, int fused) { return fused == 1 ? P + 5 : (fused == 2 ? P + 3 : P); }
+static unsigned* g_dw_bwd_amax = nullptr;       // (hand-over from ctn_dw_bwd_gln2 to the shared launcher below: one host thread at a time)
+int ctn_dw_bwd_rows(int P, int fused) { return fused == 1 ? P + 5 : (fused == 2 ? P + 3 : (fused == 3 ? P + 6 : P)); }
 
 // see include/ctn_hip.h.  pc is [F, M, H] with F = ctn_dw_bwd_rows(P, fused)
 int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, const float* D,
@@ -1334,9 +1378,9 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
     const bool small = halo <= 128, medium = !small && halo <= 256;
     const int seg = (((small ? BWD_BUF_S : (medium ? BWD_BUF_M : BWD_BUF_L)) - halo - 8) / 64) * 64;
     CTN_REQUIRE(seg >= 64, "ctn_dw_bwd: receptive field (P-1)*dilation=%d too large", halo);
-    CTN_REQUIRE(fused >= 0 && fused <= 2, "ctn_dw_bwd: fused must be 0, 1 (gLN) or 2 (cLN: ctn_dw_bwd_cln)");
-    if (fused == 1)
-        CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && sums1_part,
+    CTN_REQUIRE(fused >= 0 && fused <= 3, "ctn_dw_bwd: fused must be 0, 1 (gLN), 2 (cLN: ctn_dw_bwd_cln) or 3 (gLN + first norm's backward: ctn_dw_bwd_gln2)");
+    if (fused == 1 || fused == 3)
+        CTN_REQUIRE(Dz && g1 && b1 && a1 && ms1 && g2 && a2 && ms2 && sums2_part && sums2_nparts > 0 && (fused == 3 || sums1_part),
                     "ctn_dw_bwd: fused mode needs every norm argument");
     const bool xcln = fused == 2 && g1 != nullptr;        // the cLN form with the first norm's output recomputed from Y1 = h1
     if (fused == 2) {       // (ms2 carries the per-frame constants fc [M][4][Kp]; ms1 / sums2_part the first norm's mean / rstd [M][Kp])
@@ -1372,7 +1416,8 @@ int ctn_dw_bwd(const float* dN2, const float* Dz, const float* Y1, float* dN1, c
         if (P == 3) CTN_DW_BWD_P(D_, X_, 3);  \
         else CTN_DW_BWD_P(D_, X_, 0);         \
     } while (0)
-    if (fused == 1) CTN_DW_BWD(1, 1);
+    if (fused == 3) { a.amax_out = g_dw_bwd_amax; CTN_DW_BWD(1, 3); }
+    else if (fused == 1) CTN_DW_BWD(1, 1);
     else if (xcln) CTN_DW_BWD(2, 2);
     else if (fused == 2) CTN_DW_BWD(2, 0);
     else CTN_DW_BWD(0, 0);
@@ -1393,6 +1438,20 @@ int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* 
                        dbeta2, dgamma1, dbeta1, dalpha2, dalpha1_part, n_dalpha1, dalpha1);
     CTN_CHECK_LAUNCH("ctn_dw_bwd_finalize");
     return CTN_OK;
+}
+
+// gLN form with the first norm's backward applied (round 4): see include/ctn_hip.h.  sums2_part [M, nparts, 8] from ctn_pw_dgrad_gln2;
+// dY1 = gLN1' . PReLU1'(dN1) [M,H,Kp]; pc [P+6, M, H] (rows as fused = 1, plus P+5: dalpha1 partials); amax_out optional (h3).
+int ctn_dw_bwd_gln2(const float* dN2, const float* Dz, const float* Y1, float* dY1, const float* D,
+                    int M, int H, int K, int Kp, int P, int dilation, int causal,
+                    const float* g1, const float* b1, const float* a1, const float* ms1,
+                    const float* g2, const float* a2, const float* ms2,
+                    const double* sums2_part, int sums2_nparts, float* pc, unsigned* amax_out, void* stream) {
+    g_dw_bwd_amax = amax_out;
+    const int rc = ctn_dw_bwd(dN2, Dz, Y1, dY1, D, M, H, K, Kp, P, dilation, causal, 3, g1, b1, a1, ms1, g2, a2, ms2, sums2_part, sums2_nparts,
+                              pc, nullptr, stream);
+    g_dw_bwd_amax = nullptr;
+    return rc;
 }
 
 // cLN form (round 4): see include/ctn_hip.h
@@ -1477,6 +1536,15 @@ int ctn_cln_fuse(void) {         // (-1: not read yet; CTN_CLN_FUSE=0|1|2 at fir
         g_ctn_cln_fuse = (e && *e >= '0' && *e <= '2' && !e[1]) ? *e - '0' : 2;
     }
     return g_ctn_cln_fuse;
+}
+ // ctn_tune("gln_fuse", 0 | 1): composite gLN stacks without the gLN-1' / PReLU-1' pass (ctn_pw_dgrad_gln2 + ctn_dw_bwd_gln2)
+int g_ctn_gln_fuse = -1;
+int ctn_gln_fuse(void) {         // (CTN_GLN_FUSE=0|1 at first use; default below)
+    if (g_ctn_gln_fuse < 0) {
+        const char* e = getenv("CTN_GLN_FUSE");
+        g_ctn_gln_fuse = (e && (*e == '0' || *e == '1') && !e[1]) ? *e - '0' : 1;
+    }
+    return g_ctn_gln_fuse;
 }
 int g_ctn_cln_lean = 1;          // ctn_tune("cln_lean", 0 | 1): the specialised backward kernel for the stacks' form
 

@@ -270,6 +270,25 @@ def pw_dgrad_cln(W, dOut, R, Cn, K, y, gamma, alpha, mean, rstd, g_amax=None):
     return dn, part
 
 
+def pw_dgrad_gln2(W, dOut, R, Cn, K, y, gamma, alpha, ms, gamma1, beta1, D, dilation, causal, g_amax=None):
+    """ctn_pw_dgrad_gln2: dN = W^T . dOut (W stored [Cn, R]) + the EIGHT per-utterance sums partials from which both norms' backward
+    sums follow (include/ctn_hip.h), on the weight form the composite stack uses.  Returns (dN, sums_part [M, parts, 8] f64)."""
+    M, _, Kp = dOut.shape
+    if g_amax is not None:
+        Wp, form = h3_pieces(W, R, Cn, True), 3
+    elif _b3_planes_ok(R):
+        Wp, form = _b3_pieces(W, R, Cn, True), 2
+    else:
+        Wp, form = W, 1
+    dn = torch.empty((M, R, Kp), dtype=F32, device=dOut.device)
+    part = torch.empty((M, lib.ctn_pw_stats_parts(M, R, Kp), 8), dtype=F64, device=dOut.device)
+    _chk(dOut, y, gamma, alpha, ms, gamma1, beta1, D)
+    _chk_aux(g_amax)
+    lib.call("ctn_pw_dgrad_gln2", _p(Wp), form, _p(dOut), _p(dn), M, R, Cn, K, Kp, _p(y), _p(gamma), _p(alpha), _p(ms), _p(gamma1),
+             _p(beta1), _p(D), D.shape[-1], dilation, int(causal), _p(part), _p(g_amax), _stream())
+    return dn, part
+
+
 def pw_gemm_cln(W, X, R, Cn, K, alpha, x_amax=None):
     """ctn_pw_gemm_cln: Out = W . X (W stored [R, Cn]) + the per-frame column partials of (sum p, sum p^2), p = prelu(Out, alpha), on
     the weight form the composite stack uses.  Returns (Out, col_part [M, nparts, Kp, 2] f64)."""
@@ -607,9 +626,14 @@ class GlnBlock(torch.autograd.Function):
         # -- second 1x1: input gradient (+ gLN2 backward sums) and weight gradient
         _chk(dout, x, h1, d)
         h3 = ctx.h3
+        fuse4 = lib.ctn_gln_fuse() != 0         # no gLN-1' / PReLU-1' pass (the composite's rule; include/ctn_hip.h, "gln_fuse")
+        ady = None
         if h3 is not None:
             ax, ad = h3
             ady, gbm = absmax_rows(dout), absmax_of(g2, b2)
+        if fuse4:
+            dn2, s2p = pw_dgrad_gln2(w2, dout, H, B, K, d, g2, a2, ms2, g1, b1, D, dilation, causal, g_amax=ady)
+        elif h3 is not None:
             dn2, s2p = pw_dgrad_gln_h3(h3_pieces(w2, H, B, True), dout, H, B, K, d, g2, a2, ms2, ady)
         else:
             dn2, s2p = pw_dgrad_gln(w2, dout, H, B, K, d, g2, a2, ms2)
@@ -623,12 +647,16 @@ class GlnBlock(torch.autograd.Function):
         else:
             dW2 = pw_wgrad(dout, d, B, H, K, pro=(g2, b2, a2, ms2), out=sinks[8] if direct else None)
         # -- gLN2 <- PReLU2 <- depthwise <- gLN1 output, one pass
-        Fr = lib.ctn_dw_bwd_rows(P, 1)
+        Fr = lib.ctn_dw_bwd_rows(P, 3 if fuse4 else 1)
         pc = torch.empty((Fr, M, H), dtype=F32, device=dev)
-        s1p = torch.empty((M, H, 2), dtype=F64, device=dev)
         dn1 = torch.empty((M, H, Kp), dtype=F32, device=dev)
-        lib.call("ctn_dw_bwd", _p(dn2), _p(d), _p(h1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 1,
-                 _p(g1), _p(b1), _p(a1), _p(ms1), _p(g2), _p(a2), _p(ms2), _p(s2p), np2, _p(pc), _p(s1p), st)
+        if fuse4:       # the kernel applies the first norm's backward itself: dn1 receives dh1, pc row P + 5 the dalpha1 partials
+            lib.call("ctn_dw_bwd_gln2", _p(dn2), _p(d), _p(h1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal),
+                     _p(g1), _p(b1), _p(a1), _p(ms1), _p(g2), _p(a2), _p(ms2), _p(s2p), np2, _p(pc), 0, st)
+        else:
+            s1p = torch.empty((M, H, 2), dtype=F64, device=dev)
+            lib.call("ctn_dw_bwd", _p(dn2), _p(d), _p(h1), _p(dn1), _p(D), M, H, K, Kp, P, dilation, int(causal), 1,
+                     _p(g1), _p(b1), _p(a1), _p(ms1), _p(g2), _p(a2), _p(ms2), _p(s2p), np2, _p(pc), _p(s1p), st)
         if direct:
             _, s_a1, s_g1, s_b1, s_D, s_a2, s_g2, s_b2, _ = sinks
             dD, dg2, db2, dg1, db1, da2, da1 = s_D, s_g2, s_b2, s_g1, s_b1, s_a2, s_a1
@@ -638,8 +666,11 @@ class GlnBlock(torch.autograd.Function):
             da2 = torch.empty((1,), dtype=F32, device=dev)
             da1 = torch.empty((1,), dtype=F32, device=dev)
         # -- gLN1 + PReLU1 backward, in place on dn1
-        da1p = torch.empty((M * H,), dtype=F32, device=dev)
-        lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), 0, st)
+        if fuse4:
+            da1p = pc[P + 5].reshape(-1)
+        else:
+            da1p = torch.empty((M * H,), dtype=F32, device=dev)
+            lib.call("ctn_gln_prelu_bwd", _p(dn1), _p(h1), _p(dn1), M, H, K, Kp, _p(g1), _p(a1), _p(ms1), _p(s1p), H, _p(da1p), 0, st)
 
         # The fixed-order finishing reductions (one launch: depthwise-weight / gamma / beta / both alpha gradients) feed
         # only parameter gradients.  CTN_SIDE_FIN=1 issues them with the first layer's weight gradient on the second

@@ -100,10 +100,13 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * use); ctn_cln_fuse() reads it;
  * "bwd_events" 0|1|2 (default 0 = gLN stacks 1, cLN stacks 2; CTN_BWD_EVENTS=1|2 at first use): forks of the weight-gradient stream
  * per block of the composite backward passes -- 2: dW2 behind B1 and dW1 behind the norm backward; 1: one fork behind B5 (dW1 and the
- * sums of that block, then dW2 of the next block, which needs only that B5's output); same gradients bit for bit.  Defaults are the
+ * sums of that block, then dW2 of the next block, which needs only that B5's output); same gradients bit for bit; "gln_fuse" 0|1
+ * (CTN_GLN_FUSE at first use; ctn_gln_fuse() reads it): 1 = the composite gLN stacks run without the gLN-1' / PReLU-1' pass
+ * (ctn_pw_dgrad_gln2 + ctn_dw_bwd_gln2 instead of ctn_pw_dgrad_gln + ctn_dw_bwd + ctn_gln_prelu_bwd).  Defaults are the
  * measured best. */
 int ctn_tune(const char* key, int value);
 int ctn_cln_fuse(void);
+int ctn_gln_fuse(void);
 /* Arithmetic of the 1x1-convolution GEMMs (ctn_pw_gemm, ctn_pw_dgrad_gln, ctn_pw_wgrad and the composites over them):
  *   3 = "h3" (default): the GEMMs of the composite stacks (ctn_tcn_*) run on the ctn_*_h3 entry points below -- two fp16 pieces
  *       per fp32 operand under a tracked power-of-two scale, three f16 MFMAs, fp32 accumulation; every other GEMM as b6;
@@ -207,6 +210,30 @@ int ctn_dw_bwd_rows(int P, int fused);
 int ctn_dw_bwd_finalize(const float* pc, int P, int M, int H, float* dD, float* dgamma2, float* dbeta2,
                         float* dgamma1, float* dbeta1, float* dalpha2, const float* dalpha1_part, int n_dalpha1,
                         float* dalpha1, void* stream);
+
+/* gLN block WITHOUT the gLN-1' / PReLU-1' pass (round 4; GlobalLayerNorm backward of src/conv_tasnet.py:338-361 inside a TemporalBlock,
+ * :223-225).  The first norm's backward needs S1' = sum gamma1 dN1 and S2' = sum gamma1 dN1 xhat1 over the utterance, dN1 being the
+ * depthwise conv's input gradient.  The conv's adjoint moves both sums onto its OUTPUT gradient dd:
+ *     S1' = sum_{c,k} dd[c,k] gamma1[c] V[c,k],   S2' = sum_{c,k} dd[c,k] (d[c,k] - beta1[c] V[c,k])
+ * (d = the forward depthwise output = dw(gamma1 xhat1 + beta1), V[c,k] = sum of the taps of frame k that stay inside [0, K)), and
+ * dd = prelu'(d) rstd2 (gamma2 dN2 - c1 - xhat2 c2) is affine in the second norm's (c1, c2) -- so six more per-utterance sums of
+ * quantities that the second 1x1 conv's input-gradient GEMM already holds in its epilogue give S1', S2' BEFORE the depthwise
+ * backward runs:   ctn_pw_dgrad_gln2 = ctn_pw_dgrad_gln with sums_part [M, ctn_pw_stats_parts(M,R,Kp), 8]
+ *     (S1, S2, sum u t g1V, sum u g1V, sum u xh2 g1V, sum u t e, sum u e, sum u xh2 e;  u = prelu'(d), t = gamma2 dN, g1V = gamma1 V,
+ *      e = d - beta1 V; W / w_form as ctn_pw_dgrad_cln; gamma1, beta1 [R], D [R,P], P, dilation, causal: the depthwise conv),
+ * and ctn_dw_bwd_gln2 = ctn_dw_bwd(fused = 1) that applies the first norm's backward to its result on the fly: it writes
+ *     dY1 = rstd1 (gamma1 dN1 - S1'/n - xhat1 S2'/n) prelu'(Y1)   instead of dN1,
+ * the dalpha1 partials as row P+5 of pc [P+6, M, H] (ctn_dw_bwd_rows(P, 3); finish with ctn_dw_bwd_finalize, dalpha1_part = that
+ * row) and, with amax_out != NULL, max |dY1[m]| (h3 section).  ctn_gln_prelu_bwd (three tensor passes) is not needed then. */
+int ctn_pw_dgrad_gln2(const void* W, int w_form, const float* dOut, float* dN, int M, int R, int Cn, int K, int Kp,
+                      const float* y, const float* gamma, const float* alpha, const float* ms,
+                      const float* gamma1, const float* beta1, const float* D, int P, int dilation, int causal,
+                      double* sums_part, const unsigned* g_amax, void* stream);
+int ctn_dw_bwd_gln2(const float* dN2, const float* Dz, const float* Y1, float* dY1, const float* D,
+                    int M, int H, int K, int Kp, int P, int dilation, int causal,
+                    const float* g1, const float* b1, const float* a1, const float* ms1,
+                    const float* g2, const float* a2, const float* ms2,
+                    const double* sums2_part, int sums2_nparts, float* pc, unsigned* amax_out, void* stream);
 
 /* Fixed-order finish of the UN-fused ctn_dw_bwd's tap partials: pc [P, M, H] -> dD [H, P] (the depthwise weight's layout). */
 int ctn_dw_bwd_taps(const float* pc, int P, int M, int H, float* dD, void* stream);

@@ -228,6 +228,44 @@ def test_fused_cln_backward_equals_the_standalone_pass(B, H, K, M, dil, causal):
             assert torch.equal(u, v)
 
 
+def _gln_block_grads(B, H, K, M, dil, causal, fuse, seed=3):
+    """One gLN TemporalBlock (per-kernel path), forward + backward; fuse = ctn_tune("gln_fuse")."""
+    ctn.lib.call("ctn_tune", b"gln_fuse", int(fuse))
+    try:
+        blk = ctn.conv_tasnet.TemporalBlock(B, H, 3, 1, 0, dil, "gLN", causal).to(DEV)
+        gen = g(seed)
+        with torch.no_grad():
+            for p in blk.parameters():
+                p.copy_((torch.randn(p.shape, generator=gen) * 0.3 + (0.25 if p.numel() == 1 else 0.0)).to(DEV))
+        Kp = ops.padded_frames(K)
+        x = pad(torch.randn(M, B, K, generator=gen), Kp).to(DEV).requires_grad_(True)
+        out = blk.fused(x, K)           # ops.GlnBlock
+        dout = pad(torch.randn(M, B, K, generator=gen), Kp).to(DEV)
+        out.backward(dout)
+        return [x.grad.clone(), out.detach().clone()] + [p.grad.clone() for p in blk.parameters()]
+    finally:
+        ctn.lib.call("ctn_tune", b"gln_fuse", 1)
+
+
+@pytest.mark.parametrize("B,H,K,M,dil,causal", [(16, 32, 300, 2, 2, True), (64, 128, 799, 2, 8, False), (256, 512, 1300, 2, 128, False),
+                                                 (64, 136, 257, 3, 1, False), (64, 128, 700, 2, 64, True)])
+def test_gln_backward_without_the_norm_pass_equals_the_three_pass_chain(B, H, K, M, dil, causal):
+    """Round 4, ctn_tune("gln_fuse", 1): the first norm's backward sums S1' = sum gamma1 dn1 and S2' = sum gamma1 dn1 xhat1 are taken
+    from the second 1x1 conv's input-gradient GEMM -- the depthwise conv's adjoint moves them onto its output gradient dd, which is
+    affine in the second norm's two sums: eight per-utterance sums in that GEMM's epilogue (ctn_pw_dgrad_gln2) -- so the depthwise
+    backward can apply gLN-1' / PReLU-1' itself (ctn_dw_bwd_gln2) and the ctn_gln_prelu_bwd pass is gone.  Same mathematics: every
+    gradient agrees with the three-pass chain (0) to a few fp32 roundings, incl. edge frames (dilated taps leaving [0, K) on either
+    side, causal and not) and a ragged row tile; bitwise reproducible."""
+    ref = _gln_block_grads(B, H, K, M, dil, causal, 0)
+    a = _gln_block_grads(B, H, K, M, dil, causal, 1)
+    for i, (u, v) in enumerate(zip(a, ref)):
+        assert rel_err(u, v) < 2e-5, i
+    assert float(a[0][..., K:].abs().max()) == 0.0
+    c = _gln_block_grads(B, H, K, M, dil, causal, 1)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+
+
 def test_cln_forward_statistics_from_the_gemm_epilogue_against_fp64():
     """ctn_pw_gemm_cln + ctn_cln_stats_frame against fp64 torch: Out, and (mean, rstd) per frame of prelu(Out) over channels."""
     M, R, Cn, K = 2, 192, 64, 333
