@@ -1542,7 +1542,7 @@ int g_ctn_gln_fuse = -1;
 int ctn_gln_fuse(void) {         // (CTN_GLN_FUSE=0|1 at first use; default below)
     if (g_ctn_gln_fuse < 0) {
         const char* e = getenv("CTN_GLN_FUSE");
-        g_ctn_gln_fuse = (e && (*e == '0' || *e == '1') && !e[1]) ? *e - '0' : 1;
+        g_ctn_gln_fuse = (e && (*e == '0' || *e == '1') && !e[1]) ? *e - '0' : 0;      // measured slower in the step (profiles/README.md r04_m): off
     }
     return g_ctn_gln_fuse;
 }

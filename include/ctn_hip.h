@@ -101,8 +101,9 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * "bwd_events" 0|1|2 (default 0 = gLN stacks 1, cLN stacks 2; CTN_BWD_EVENTS=1|2 at first use): forks of the weight-gradient stream
  * per block of the composite backward passes -- 2: dW2 behind B1 and dW1 behind the norm backward; 1: one fork behind B5 (dW1 and the
  * sums of that block, then dW2 of the next block, which needs only that B5's output); same gradients bit for bit; "gln_fuse" 0|1
- * (CTN_GLN_FUSE at first use; ctn_gln_fuse() reads it): 1 = the composite gLN stacks run without the gLN-1' / PReLU-1' pass
- * (ctn_pw_dgrad_gln2 + ctn_dw_bwd_gln2 instead of ctn_pw_dgrad_gln + ctn_dw_bwd + ctn_gln_prelu_bwd).  Defaults are the
+ * (default 0; CTN_GLN_FUSE at first use; ctn_gln_fuse() reads it): 1 = the composite gLN stacks run without the gLN-1' / PReLU-1' pass
+ * (ctn_pw_dgrad_gln2 + ctn_dw_bwd_gln2 instead of ctn_pw_dgrad_gln + ctn_dw_bwd + ctn_gln_prelu_bwd): three tensor passes of 20 less, same
+ * gradients to fp32 rounding -- and 2-3 % SLOWER in the step (the six extra sums make the GEMM's epilogue 20 us longer): a tested option.  Defaults are the
  * measured best. */
 int ctn_tune(const char* key, int value);
 int ctn_cln_fuse(void);

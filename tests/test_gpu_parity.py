@@ -244,13 +244,13 @@ def _gln_block_grads(B, H, K, M, dil, causal, fuse, seed=3):
         out.backward(dout)
         return [x.grad.clone(), out.detach().clone()] + [p.grad.clone() for p in blk.parameters()]
     finally:
-        ctn.lib.call("ctn_tune", b"gln_fuse", 1)
+        ctn.lib.call("ctn_tune", b"gln_fuse", 0)           # the default
 
 
 @pytest.mark.parametrize("B,H,K,M,dil,causal", [(16, 32, 300, 2, 2, True), (64, 128, 799, 2, 8, False), (256, 512, 1300, 2, 128, False),
                                                  (64, 136, 257, 3, 1, False), (64, 128, 700, 2, 64, True)])
 def test_gln_backward_without_the_norm_pass_equals_the_three_pass_chain(B, H, K, M, dil, causal):
-    """Round 4, ctn_tune("gln_fuse", 1): the first norm's backward sums S1' = sum gamma1 dn1 and S2' = sum gamma1 dn1 xhat1 are taken
+    """Round 4, ctn_tune("gln_fuse", 1) (opt-in: correct, measured 2-3 % slower in the step): the first norm's backward sums S1' = sum gamma1 dn1 and S2' = sum gamma1 dn1 xhat1 are taken
     from the second 1x1 conv's input-gradient GEMM -- the depthwise conv's adjoint moves them onto its output gradient dd, which is
     affine in the second norm's two sums: eight per-utterance sums in that GEMM's epilogue (ctn_pw_dgrad_gln2) -- so the depthwise
     backward can apply gLN-1' / PReLU-1' itself (ctn_dw_bwd_gln2) and the ctn_gln_prelu_bwd pass is gone.  Same mathematics: every
