@@ -155,12 +155,30 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     __amdgpu_buffer_rsrc_t rsG1 = rsOut, rsB1 = rsOut, rsD = rsOut;
     float q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f, q8 = 0.f;
     bool interior = false;
+    // per-row constants of the tile in LDS, loaded once per workgroup: (gamma2, gamma1, beta1, sum of the taps) and the taps themselves --
+    // per-pass global loads of them (five more VMEM instructions per pass) made this epilogue 14-19 us slower per launch
+    __shared__ float rowc[EPI == EPI_GLN_BWD2 ? TM : 1][4];
+    __shared__ float rowt[EPI == EPI_GLN_BWD2 ? TM : 1][8];
     if constexpr (EPI == EPI_GLN_BWD2) {
         rsG1 = make_rsrc(a.g1, (unsigned)a.R * 4u);
         rsB1 = make_rsrc(a.b1, (unsigned)a.R * 4u);
         rsD = make_rsrc(a.dw_D, (unsigned)a.R * (unsigned)a.dw_P * 4u);
         // every tap of every frame of this tile inside [0, K): V = sum of the taps (uniform over the workgroup)
         interior = c0 - a.dw_padl >= 0 && c0 + TN - 1 + (a.dw_P - 1) * a.dw_dil - a.dw_padl < a.K;
+        for (int r = tid; r < TM; r += TL::NTH) {
+            float ts = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float tj = j < a.dw_P ? buf_ld1(rsD, ((r0 + r) * a.dw_P + j) * 4, 0) : 0.f;
+                rowt[r][j] = tj;
+                ts += tj;
+            }
+            rowc[r][0] = buf_ld1(rsGam, (r0 + r) * 4, 0);
+            rowc[r][1] = buf_ld1(rsG1, (r0 + r) * 4, 0);
+            rowc[r][2] = buf_ld1(rsB1, (r0 + r) * 4, 0);
+            rowc[r][3] = ts;
+        }
+        __syncthreads();
     }
     const bool ragged = c0 + TN > a.Kp;     // uniform
     const int rl0 = lane / C4, cl = (lane % C4) * 4;
@@ -221,38 +239,34 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
                 }
                 if constexpr (EPI == EPI_GLN_BWD2) {
                     const float4 y = buf_ld4(rsAux, vo0, so);
-                    const int rrow = r0 + wm * WM + rl0, rso = mt * 32 + p * RPP;          // row = rrow + rso
-                    const float g = buf_ld1(rsGam, rrow * 4, rso * 4);
-                    const float g1v = buf_ld1(rsG1, rrow * 4, rso * 4), b1v = buf_ld1(rsB1, rrow * 4, rso * 4);
-                    float tap[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) tap[j] = j < a.dw_P ? buf_ld1(rsD, (rrow * a.dw_P + j) * 4, rso * a.dw_P * 4) : 0.f;
+                    const int rloc = wm * WM + mt * 32 + rl;                    // row of this pass inside the tile
+                    const float4 rc = *reinterpret_cast<const float4*>(&rowc[rloc][0]);
+                    const float g = rc.x, g1v = rc.y, b1v = rc.z;
                     const float vv[4] = {v.x, v.y, v.z, v.w}, yy[4] = {y.x, y.y, y.z, y.w};
-                    float Vs = 0.f;
+                    // V of this thread's four frames: the sum of the taps whose source frame lies in [0, K)
+                    float V[4] = {rc.w, rc.w, rc.w, rc.w};
+                    if (!interior) {                                            // (uniform; 2-5 of 50 column tiles)
+                        V[0] = V[1] = V[2] = V[3] = 0.f;
+#pragma unroll 1
+                        for (int j = 0; j < a.dw_P; ++j) {
+                            const float tj = rowt[rloc][j];
+                            const int k0 = kcol + j * a.dw_dil - a.dw_padl;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Vs += tap[j];
+                            for (int e = 0; e < 4; ++e) V[e] += (k0 + e >= 0 && k0 + e < a.K) ? tj : 0.f;
+                        }
+                    }
+                    // with u = prelu'(y): u y = prelu(y) = pp, so  sum u (y - b1 V) f = sum pp f - b1 sum u V f  for f in {t, 1, xh}
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float V = Vs;
-                        if (!interior) {
-                            V = 0.f;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int kk = kcol + e + j * a.dw_dil - a.dw_padl;
-                                if (j < a.dw_P && kk >= 0 && kk < a.K) V += tap[j];
-                            }
-                        }
-                        const float t = g * vv[e];
-                        const float xh = (prelu_f(yy[e], e_alpha) - b_mean) * b_rstd;
+                        const float t = g * vv[e], pp = prelu_f(yy[e], e_alpha);
+                        const float xh = (pp - b_mean) * b_rstd;
                         s1 += t;
                         s2 += t * xh;
-                        if (kcol + e < a.K) {           // (frames >= K: t = 0, but the terms without t are not)
-                            const float u = yy[e] >= 0.f ? 1.f : e_alpha;
-                            const float w1 = g1v * V, w2 = yy[e] - b1v * V;
-                            const float ut = u * t, ux = u * xh;
-                            q3 += ut * w1; q4 += u * w1; q5 += ux * w1;
-                            q6 += ut * w2; q7 += u * w2; q8 += ux * w2;
-                        }
+                        const float ok = kcol + e < a.K ? 1.f : 0.f;            // (frames >= K: t = 0, but the terms without t are not)
+                        const float u = yy[e] >= 0.f ? ok : ok * e_alpha, uV = u * V[e];
+                        const float w1 = g1v * uV, w2 = ok * pp - b1v * uV;     // u g1 V  and  u (y - b1 V)
+                        q3 += w1 * t; q4 += w1; q5 += w1 * xh;
+                        q6 += w2 * t; q7 += w2; q8 += w2 * xh;
                     }
                 }
                 if constexpr (EPI == EPI_CLN_BWD) {
@@ -320,12 +334,23 @@ __device__ __forceinline__ void gemm_epilogue(const PwArgs& a, f32x16 (&acc)[TL:
     }
     if constexpr (EPI == EPI_GLN_BWD2) {
         // (rows >= R: gamma2 and gamma1 read 0 and y reads 0 -> t = 0, w1 = 0, w2 = -b1 V = 0 as beta1 reads 0 too: exact zeros)
+        // the eight sums in ONE block reduction (two barriers instead of sixteen): fp64 over the lanes, then over the waves in wave order
         const float qs[8] = {s1, s2, q3, q4, q5, q6, q7, q8};
-        double* const dst = a.bwd_part + ((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 8;
+        double* const sc8 = reinterpret_cast<double*>(smem);         // [8][NW]; the staging patches are free after the barrier
+        double w8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double di = block_sum<double, TL::NTH>((double)qs[i], red);
-            if (tid == 0) dst[i] = di;
+        for (int i = 0; i < 8; ++i) w8[i] = wave_sum((double)qs[i]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sc8[i * TL::NW + wave] = w8[i];
+        }
+        __syncthreads();
+        if (tid < 8) {
+            double r = sc8[tid * TL::NW];
+#pragma unroll
+            for (int w = 1; w < TL::NW; ++w) r += sc8[tid * TL::NW + w];
+            a.bwd_part[((size_t)m * (a.tiles_r * a.tiles_c) + (size_t)ct * a.tiles_r + rt) * 8 + tid] = r;
         }
     }
     if constexpr (EPI == EPI_PRELU_STATS || EPI == EPI_GLN_BWD) {

@@ -242,8 +242,26 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(DwBwdArgs a) {
         for (int i = tid; i < a.sums2_nparts; i += NT)
 #pragma unroll
             for (int q = 0; q < NS; ++q) S[q] += a.sums2_part[((size_t)m * a.sums2_nparts + i) * NS + q];
+        if constexpr (APPLY) {          // the eight sums in one reduction (two barriers): fp64 over the lanes, then over the waves in order
+            __shared__ double red8[8][NT / 64];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) S[q] = block_sum<double, NT>(S[q], red);
+            for (int q = 0; q < NS; ++q) S[q] = wave_sum(S[q]);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) red8[q][wave] = S[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                double r = red8[q][0];
+#pragma unroll
+                for (int w2 = 1; w2 < NT / 64; ++w2) r += red8[q][w2];
+                S[q] = r;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) S[q] = block_sum<double, NT>(S[q], red);
+        }
         const double n = (double)a.H * (double)a.K;
         const double d1 = S[0] / n, d2 = S[1] / n;
         c1 = (float)d1;

@@ -103,7 +103,7 @@ size_t ctn_pw_wgrad_workspace(int M, int R, int Cn, int Kp);
  * sums of that block, then dW2 of the next block, which needs only that B5's output); same gradients bit for bit; "gln_fuse" 0|1
  * (default 0; CTN_GLN_FUSE at first use; ctn_gln_fuse() reads it): 1 = the composite gLN stacks run without the gLN-1' / PReLU-1' pass
  * (ctn_pw_dgrad_gln2 + ctn_dw_bwd_gln2 instead of ctn_pw_dgrad_gln + ctn_dw_bwd + ctn_gln_prelu_bwd): three tensor passes of 20 less, same
- * gradients to fp32 rounding -- and 2-3 % SLOWER in the step (the six extra sums make the GEMM's epilogue 20 us longer): a tested option.  Defaults are the
+ * gradients to fp32 rounding -- and 1.7 % SLOWER in the step (profiles/README.md r04_m): a tested option.  Defaults are the
  * measured best. */
 int ctn_tune(const char* key, int value);
 int ctn_cln_fuse(void);
