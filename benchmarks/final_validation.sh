@@ -31,6 +31,9 @@ cd $R
 cp $(ls gpurun_out/prof_${T}/*kernel_stats.csv gpurun_out/prof_${T}/*/*kernel_stats.csv 2>/dev/null | head -1) gpurun_out/${T}_kernel_stats_bench_steps5.csv
 python benchmarks/kstats.py gpurun_out/prof_${T} 7 14
 bash benchmarks/pmc_traffic.sh pw_wgrad_b3_kernel benchmarks/gemm_only.py gpurun_out/${T%%_*}_pmc_h3_wgrad_dW2_pro.json "B2 weight gradient dW2 (gLN prologue)" "W2 30" h3 | tail -12
+bash benchmarks/pmc_traffic.sh pw_wgrad_b3_kernel benchmarks/gemm_only.py gpurun_out/${T%%_*}_pmc_h3_wgrad_dW1.json "B6 weight gradient dW1 + slab_reduce" "W1 30" h3 | tail -4
+bash benchmarks/pmc_traffic.sh pw_gemm_b3p_kernel benchmarks/gemm_only.py gpurun_out/${T%%_*}_pmc_h3_K3.json "K3 1x1 H->B (gLN prologue + residual)" "K3 30" h3 | tail -4
+bash benchmarks/pmc_traffic.sh pw_gemm_b3p_kernel benchmarks/gemm_only.py gpurun_out/${T%%_*}_pmc_h3_K1.json "K1 1x1 B->H (+ PReLU/gLN statistics)" "K1 30" h3 | tail -4
 bash benchmarks/pmc_traffic.sh pw_gemm_b3p_kernel benchmarks/gemm_only.py gpurun_out/${T%%_*}_pmc_h3_B1.json "B1 input gradient W2^T.dout (+ gLN backward sums)" "B1 30" h3 | tail -4
 bash benchmarks/pmc_traffic.sh dw_bwd_kernel benchmarks/dw_bwd_only.py gpurun_out/${T%%_*}_pmc_dw_bwd.json "B3 dw_bwd fused (gLN2'.PReLU2'.dw^T)" "8" any | tail -4
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
